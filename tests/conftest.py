@@ -1,0 +1,30 @@
+"""pytest configuration: the ``gpu`` marker and import paths.
+
+``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI symbol check.
+``-m gpu``: parity tests proper, through the C-ABI on a real MI355X.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "3d-reconstruction-from-multi-view-exp_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+    return load
