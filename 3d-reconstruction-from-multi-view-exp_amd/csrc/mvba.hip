@@ -1,0 +1,1018 @@
+// libmvba.so -- bundle-adjustment engine for MI355X (gfx950), hand-written HIP.
+//
+// Replaces the numerical body of the reference's BundleAdjuster.optimize
+// (lib/bundle_adjustment.py:103-162) with a sparse, observation-list pipeline:
+//   K1  k_resid_jac      residual + 2x3 / 2x9 Jacobian rows per observation   (ref :291-427)
+//   K2  k_point_blocks   E_a = 2 sum JxT Jx, dP_a = 2 sum JxT e               (ref :429-469, :519-556)
+//   K3a k_point_inv      damped 3x3 inverse, v_a = E^-1 dP_a                  (ref :120-128)
+//   K3  k_schur_strip    A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
+//   C1  ncclAllReduce    [A|b] across point shards                            
+//   K4  k_chol_* / trsv  dense solve of the gauge-reduced system              (ref :146)
+//   K5+K6 k_backsub_cost dX_a, trial state, trial cost                        (ref :152-162, :260-281, :666-677)
+// HBM layout: observations sorted by point (CSR); every per-observation product
+// is a set of double2 "planes" plane[p][obs] = (row0[p], row1[p]) so that one
+// wave moves 1 KiB per load/store instruction: e (1 plane), J_X (3), J_C (9).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mvba_common.h"
+
+namespace mvba {
+thread_local std::string g_err;
+}
+using namespace mvba;
+
+// ------------------------------------------------------------------ device helpers
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the sum; fixed tree -> deterministic
+}
+
+// Deterministic block sum (fixed tree); result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *s_red /*[16]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) s_red[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += s_red[i];
+  }
+  return t;
+}
+
+__device__ __forceinline__ void load_cams_to_lds(const double *__restrict__ cam15, int m, double f0,
+                                                 double *s_cam) {
+  for (int k = threadIdx.x; k < m; k += blockDim.x) expand_cam(cam15 + (size_t)k * CAM_IN, f0, s_cam + k * CAM_LDS);
+}
+
+__device__ __forceinline__ int keep_index(int i, int gauge_axis) {
+  // i-th kept parameter -> global parameter index; removed = {3..8, 12+axis} (ref :62-72)
+  if (i < 3) return i;
+  return (i + 6 < 12 + gauge_axis) ? i + 6 : i + 7;
+}
+
+// ------------------------------------------------------------------ K1
+// One thread per observation, grid-stride; camera table staged once per block.
+// Algorithmic traffic: 24 B in + 208 B out per observation + 24 B per point.
+__global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
+                                                   const double *__restrict__ X,
+                                                   const int *__restrict__ obs_pt,
+                                                   const int *__restrict__ cam_idx,
+                                                   const double2 *__restrict__ xy, double f0,
+                                                   double2 *__restrict__ e, double2 *__restrict__ JX,
+                                                   double2 *__restrict__ JC) {
+  extern __shared__ double s_cam[];
+  load_cams_to_lds(cam15, m, f0, s_cam);
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < nobs; o += stride) {
+    const int a = obs_pt[o], k = cam_idx[o];
+    const double2 z = xy[o];
+    const double *Xa = X + 3 * (size_t)a;
+    ObsJ J;
+    obs_math(Xa[0], Xa[1], Xa[2], s_cam + k * CAM_LDS, z.x, z.y, f0, J);
+    e[o] = make_double2(J.e0, J.e1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) JX[(size_t)p * nobs + o] = make_double2(J.jx[0][p], J.jx[1][p]);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) JC[(size_t)p * nobs + o] = make_double2(J.jc[0][p], J.jc[1][p]);
+  }
+}
+
+// ------------------------------------------------------------------ K2
+// One thread per point: E_a (6 unique), dP_a (3).  PL[a][9] = Exx,Exy,Exz,Eyy,Eyz,Ezz,dP0..2
+__global__ __launch_bounds__(256) void k_point_blocks(long long npts, long long nobs,
+                                                      const long long *__restrict__ pt_ptr,
+                                                      const double2 *__restrict__ e,
+                                                      const double2 *__restrict__ JX, double *__restrict__ PL) {
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= npts) return;
+  double E[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (long long o = pt_ptr[a]; o < pt_ptr[a + 1]; ++o) {
+    const double2 r = e[o], x0 = JX[o], x1 = JX[nobs + o], x2 = JX[2 * nobs + o];
+    E[0] += x0.x * x0.x + x0.y * x0.y;
+    E[1] += x0.x * x1.x + x0.y * x1.y;
+    E[2] += x0.x * x2.x + x0.y * x2.y;
+    E[3] += x1.x * x1.x + x1.y * x1.y;
+    E[4] += x1.x * x2.x + x1.y * x2.y;
+    E[5] += x2.x * x2.x + x2.y * x2.y;
+    g[0] += x0.x * r.x + x0.y * r.y;
+    g[1] += x1.x * r.x + x1.y * r.y;
+    g[2] += x2.x * r.x + x2.y * r.y;
+  }
+  double *out = PL + 9 * a;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = 2.0 * E[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[6 + i] = 2.0 * g[i];
+}
+
+// ------------------------------------------------------------------ K3a
+// PB[a][10] = inverse of E_a with diagonal*(1+c) (6 unique), v_a = E^-1 dP_a (3), pad.
+__global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
+                                                   double *__restrict__ PB, int *__restrict__ flag) {
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= npts) return;
+  const double *in = PL + 9 * a;
+  const double s = 1.0 + c;
+  const double xx = in[0] * s, xy = in[1], xz = in[2], yy = in[3] * s, yz = in[4], zz = in[5] * s;
+  const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
+  const double det = xx * c00 + xy * c01 + xz * c02;
+  if (!(det != 0.0) || !isfinite(det)) atomicOr(flag, 1);  // singular 3x3 (ref :128 raises LinAlgError)
+  const double id = 1.0 / det;
+  const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+  const double i11 = (xx * zz - xz * xz) * id, i12 = (xy * xz - xx * yz) * id, i22 = (xx * yy - xy * xy) * id;
+  double *out = PB + 10 * a;
+  out[0] = i00; out[1] = i01; out[2] = i02; out[3] = i11; out[4] = i12; out[5] = i22;
+  const double g0 = in[6], g1 = in[7], g2 = in[8];
+  out[6] = i00 * g0 + i01 * g1 + i02 * g2;
+  out[7] = i01 * g0 + i11 * g1 + i12 * g2;
+  out[8] = i02 * g0 + i12 * g1 + i22 * g2;
+  out[9] = 0.0;
+}
+
+// ------------------------------------------------------------------ K3
+// Block (k, chunk, seg): accumulates the block-row strip A[9k..9k+8][9 l_lo .. 9 l_hi)
+// (l >= k: upper block triangle only) in LDS over the points of `chunk` seen by
+// camera k, then flushes it once.  Each wave walks camera-major records
+// (obs, point, remaining-observations-in-row); the k-side operands are wave-uniform
+// (scalar loads), the l-side operands are per lane: lane = 9*slot + j handles
+// column j of the 9x9 block of the slot-th remaining observation of the point.
+//   -(F_ak^T E^-1 F_al)[i][j] = -Jc_k[:,i] . ( 2 Jx_k E^-1 ( 2 Jx_l^T Jc_l[:,j] ) )
+// The diagonal item (l == k) also adds G^_k (ref :618-664 with :123-125 damping)
+// and the right-hand side 2 Jc_k^T (Jx_k v_a - e_ak)   (ref :138-143, :471-517).
+__global__ __launch_bounds__(1024) void k_schur_strip(
+    int m, int nchunks, int lseg, long long nobs, const long long *__restrict__ chunk_ptr,
+    const int4 *__restrict__ csc, const int *__restrict__ cam_idx, const double2 *__restrict__ e,
+    const double2 *__restrict__ JX, const double2 *__restrict__ JC, const double *__restrict__ PB, double c,
+    double *__restrict__ Afull, double *__restrict__ bfull) {
+  extern __shared__ double strip[];
+  const int k = blockIdx.x, chunk = blockIdx.y, seg = blockIdx.z;
+  const int l_lo = k + seg * lseg;
+  if (l_lo >= m) return;
+  const int l_hi = min(m, l_lo + lseg);
+  const int W = 9 * (l_hi - l_lo);
+  double *sb = strip + 9 * W;
+  for (int i = threadIdx.x; i < 9 * W + 9; i += blockDim.x) strip[i] = 0.0;
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 9, j = lane - 9 * slot;
+  const long long beg = chunk_ptr[(size_t)k * (nchunks + 1) + chunk];
+  const long long end = chunk_ptr[(size_t)k * (nchunks + 1) + chunk + 1];
+  const double damp = 1.0 + c;
+
+  for (long long idx = beg + wave; idx < end; idx += nw) {
+    const int4 rec = csc[idx];  // wave-uniform
+    const int o = rec.x, a = rec.y, nrem = rec.z;
+    double2 jxk[3], jck[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) jxk[p] = JX[(size_t)p * nobs + o];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) jck[p] = JC[(size_t)p * nobs + o];
+    const double2 ek = e[o];
+    const double *pb = PB + 10 * (size_t)a;
+    const double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
+    const double v0 = pb[6], v1 = pb[7], v2 = pb[8];
+    for (int base = 0; base < nrem; base += 7) {
+      const int it = base + slot;
+      if (slot < 7 && it < nrem) {
+        const int ol = o + it;
+        const int l = cam_idx[ol];
+        if (l >= l_lo && l < l_hi) {
+          const double2 x0 = JX[ol], x1 = JX[nobs + ol], x2 = JX[2 * nobs + ol];
+          const double2 cj = JC[(size_t)j * nobs + ol];
+          const double g0 = 2.0 * (x0.x * cj.x + x0.y * cj.y);  // F_al[:, j]
+          const double g1 = 2.0 * (x1.x * cj.x + x1.y * cj.y);
+          const double g2 = 2.0 * (x2.x * cj.x + x2.y * cj.y);
+          const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // E^-1 F_al[:, j]
+          const double h1 = i01 * g0 + i11 * g1 + i12 * g2;
+          const double h2 = i02 * g0 + i12 * g1 + i22 * g2;
+          const double t0 = 2.0 * (jxk[0].x * h0 + jxk[1].x * h1 + jxk[2].x * h2);
+          const double t1 = 2.0 * (jxk[0].y * h0 + jxk[1].y * h1 + jxk[2].y * h2);
+          const int col = 9 * (l - l_lo) + j;
+          const bool diag = (it == 0);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            double val = -(jck[i].x * t0 + jck[i].y * t1);
+            if (diag) {
+              double gg = 2.0 * (jck[i].x * cj.x + jck[i].y * cj.y);
+              if (i == j) gg *= damp;
+              val += gg;
+            }
+            atomicAdd(&strip[i * W + col], val);
+          }
+          if (diag) {
+            const double w0 = jxk[0].x * v0 + jxk[1].x * v1 + jxk[2].x * v2 - ek.x;
+            const double w1 = jxk[0].y * v0 + jxk[1].y * v1 + jxk[2].y * v2 - ek.y;
+            atomicAdd(&sb[j], 2.0 * (cj.x * w0 + cj.y * w1));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const size_t ld = 9 * (size_t)m;
+  for (int i = threadIdx.x; i < 9 * W; i += blockDim.x) {
+    const int row = i / W, col = i - row * W;
+    const double val = strip[i];
+    if (val != 0.0) atomicAdd(&Afull[(9 * (size_t)k + row) * ld + 9 * (size_t)l_lo + col], val);
+  }
+  if (seg == 0 && threadIdx.x < 9) atomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ K4: gauge strip + Cholesky
+__global__ void k_compact(int D, int m, int gauge_axis, const double *__restrict__ Afull,
+                          const double *__restrict__ bfull, double *__restrict__ Ared,
+                          double *__restrict__ bred) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= D) return;
+  const int gi = keep_index(i, gauge_axis), gj = keep_index(j, gauge_axis);
+  const size_t ld = 9 * (size_t)m;
+  // only the upper block triangle of Afull is populated: read (min,max)
+  const int r = min(gi, gj), cidx = max(gi, gj);
+  Ared[(size_t)i * D + j] = Afull[(size_t)r * ld + cidx];
+  if (j == 0) bred[i] = bfull[gi];
+}
+
+constexpr int NB = 32;
+
+// factor the nb x nb diagonal block at (j0,j0), lower, in place
+__global__ __launch_bounds__(1024) void k_chol_diag(double *A, int D, int j0, int nb, int *flag) {
+  __shared__ double T[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const bool in = r < nb && c < nb;
+  T[r][c] = in ? A[(size_t)(j0 + r) * D + j0 + c] : (r == c ? 1.0 : 0.0);
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    if (r == k && c == k) {
+      const double d = T[k][k];
+      if (!(d > 0.0)) atomicOr(flag, 2);  // not SPD -> reported as singular
+      T[k][k] = sqrt(d);
+    }
+    __syncthreads();
+    if (c == k && r > k) T[r][k] /= T[k][k];
+    __syncthreads();
+    if (r > k && c > k && c <= r) T[r][c] -= T[r][k] * T[c][k];
+    __syncthreads();
+  }
+  if (in && c <= r) A[(size_t)(j0 + r) * D + j0 + c] = T[r][c];
+}
+
+// rows below the diagonal block: X = P L^-T
+__global__ __launch_bounds__(1024) void k_chol_panel(double *A, int D, int j0, int nb) {
+  __shared__ double L[NB][NB + 1], P[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int row = j0 + nb + blockIdx.x * NB + r;
+  L[r][c] = (r < nb && c < nb) ? A[(size_t)(j0 + r) * D + j0 + c] : (r == c ? 1.0 : 0.0);
+  P[r][c] = (row < D && c < nb) ? A[(size_t)row * D + j0 + c] : 0.0;
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    if (c == k) P[r][k] /= L[k][k];
+    __syncthreads();
+    if (c > k) P[r][c] -= P[r][k] * L[c][k];
+    __syncthreads();
+  }
+  if (row < D && c < nb) A[(size_t)row * D + j0 + c] = P[r][c];
+}
+
+// trailing update, lower tiles only: A[r][c] -= sum_k P[r][k] P[c][k]
+__global__ __launch_bounds__(1024) void k_chol_trail(double *A, int D, int j0, int nb) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  __shared__ double Pi[NB][NB + 1], Pj[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int t0 = j0 + nb;
+  const int gr = t0 + ti * NB + r, gc0 = t0 + tj * NB + r;
+  Pi[r][c] = (gr < D && c < nb) ? A[(size_t)gr * D + j0 + c] : 0.0;
+  Pj[r][c] = (gc0 < D && c < nb) ? A[(size_t)gc0 * D + j0 + c] : 0.0;
+  __syncthreads();
+  const int gc = t0 + tj * NB + c;
+  if (gr < D && gc < D && gc <= gr) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) s += Pi[r][k] * Pj[c][k];
+    A[(size_t)gr * D + gc] -= s;
+  }
+}
+
+// L y = b then L^T x = y, single block; then scatter to the full 9m vector.
+__global__ __launch_bounds__(1024) void k_chol_solve(const double *__restrict__ L, int D, const double *__restrict__ b,
+                                                     int m, int gauge_axis, double *__restrict__ dxi_full) {
+  extern __shared__ double y[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D; i += blockDim.x) y[i] = b[i];
+  __syncthreads();
+  for (int jb = 0; jb < D; jb += NB) {  // forward
+    const int nb = min(NB, D - jb);
+    if (wave == 0) {
+      double yr = (lane < nb) ? y[jb + lane] : 0.0;
+      for (int k = 0; k < nb; ++k) {
+        const double yk = __shfl(yr, k, 64) / L[(size_t)(jb + k) * D + jb + k];
+        if (lane == k) yr = yk;
+        if (lane > k && lane < nb) yr -= L[(size_t)(jb + lane) * D + jb + k] * yk;
+      }
+      if (lane < nb) y[jb + lane] = yr;
+    }
+    __syncthreads();
+    for (int r = jb + nb + tid; r < D; r += blockDim.x) {
+      double s = 0.0;
+      for (int cc = 0; cc < nb; ++cc) s += L[(size_t)r * D + jb + cc] * y[jb + cc];
+      y[r] -= s;
+    }
+    __syncthreads();
+  }
+  const int nblk = (D + NB - 1) / NB;
+  for (int bi = nblk - 1; bi >= 0; --bi) {  // backward with L^T
+    const int jb = bi * NB, nb = min(NB, D - jb);
+    if (wave == 0) {
+      double xr = (lane < nb) ? y[jb + lane] : 0.0;
+      for (int k = nb - 1; k >= 0; --k) {
+        const double xk = __shfl(xr, k, 64) / L[(size_t)(jb + k) * D + jb + k];
+        if (lane == k) xr = xk;
+        if (lane < k) xr -= L[(size_t)(jb + k) * D + jb + lane] * xk;
+      }
+      if (lane < nb) y[jb + lane] = xr;
+    }
+    __syncthreads();
+    for (int cc = tid; cc < jb; cc += blockDim.x) {
+      double s = 0.0;
+      for (int r = 0; r < nb; ++r) s += L[(size_t)(jb + r) * D + cc] * y[jb + r];
+      y[cc] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < D; i += blockDim.x) dxi_full[keep_index(i, gauge_axis)] = y[i];
+}
+
+// ------------------------------------------------------------------ K6a: trial cameras (ref :263-281, utils.py:10-29)
+__global__ void k_update_cams(int m, const double *__restrict__ cam15, const double *__restrict__ dxi,
+                              double *__restrict__ out15) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const double *in = cam15 + (size_t)k * CAM_IN, *d = dxi + 9 * (size_t)k;
+  double *o = out15 + (size_t)k * CAM_IN;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o[i] = in[i] + d[i];
+  const double w0 = d[6], w1 = d[7], w2 = d[8];
+  if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) {  // exact-zero shortcut (utils.py:14-15)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[6 + i] = in[6 + i];
+    return;
+  }
+  const double th = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+  const double n0 = w0 / th, n1 = w1 / th, n2 = w2 / th;
+  const double cs = cos(th), sn = sin(th), oc = 1.0 - cs;
+  const double Q[9] = {oc * n0 * n0 + cs,      oc * n0 * n1 - sn * n2, oc * n0 * n2 + sn * n1,
+                       oc * n1 * n0 + sn * n2, oc * n1 * n1 + cs,      oc * n1 * n2 - sn * n0,
+                       oc * n2 * n0 - sn * n1, oc * n2 * n1 + sn * n0, oc * n2 * n2 + cs};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+      o[6 + 3 * r + cc] = Q[3 * r] * in[6 + cc] + Q[3 * r + 1] * in[9 + cc] + Q[3 * r + 2] * in[12 + cc];
+}
+
+// ------------------------------------------------------------------ K5+K6
+// One thread per point: dX_a = -E^-1 (sum_k F_ak dxi_k + dP_a), X' = X + dX, then the
+// point's residuals at the trial cameras.  partials[block] = block cost (fixed tree).
+__global__ __launch_bounds__(256) void k_backsub_cost(
+    long long npts, long long nobs, int m, const long long *__restrict__ pt_ptr, const int *__restrict__ cam_idx,
+    const double2 *__restrict__ xy, const double2 *__restrict__ JX, const double2 *__restrict__ JC,
+    const double *__restrict__ PB, const double *__restrict__ dxi, const double *__restrict__ X,
+    const double *__restrict__ cam15_trial, double f0, double *__restrict__ Xt, double *__restrict__ dX,
+    double *__restrict__ partials) {
+  extern __shared__ double smem[];
+  double *s_dxi = smem, *s_cam = smem + 9 * m;
+  __shared__ double s_red[16];
+  for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
+  load_cams_to_lds(cam15_trial, m, f0, s_cam);
+  __syncthreads();
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (a < npts) {
+    const long long o0 = pt_ptr[a], o1 = pt_ptr[a + 1];
+    double acc0 = 0, acc1 = 0, acc2 = 0;
+    for (long long o = o0; o < o1; ++o) {
+      const double *dk = s_dxi + 9 * cam_idx[o];
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const double2 cj = JC[(size_t)p * nobs + o];
+        s0 += cj.x * dk[p];
+        s1 += cj.y * dk[p];
+      }
+      const double2 x0 = JX[o], x1 = JX[nobs + o], x2 = JX[2 * nobs + o];
+      acc0 += 2.0 * (x0.x * s0 + x0.y * s1);
+      acc1 += 2.0 * (x1.x * s0 + x1.y * s1);
+      acc2 += 2.0 * (x2.x * s0 + x2.y * s1);
+    }
+    const double *pb = PB + 10 * a;
+    const double d0 = -(pb[0] * acc0 + pb[1] * acc1 + pb[2] * acc2) - pb[6];
+    const double d1 = -(pb[1] * acc0 + pb[3] * acc1 + pb[4] * acc2) - pb[7];
+    const double d2 = -(pb[2] * acc0 + pb[4] * acc1 + pb[5] * acc2) - pb[8];
+    const double X0 = X[3 * a] + d0, X1 = X[3 * a + 1] + d1, X2 = X[3 * a + 2] + d2;
+    dX[3 * a] = d0; dX[3 * a + 1] = d1; dX[3 * a + 2] = d2;
+    Xt[3 * a] = X0; Xt[3 * a + 1] = X1; Xt[3 * a + 2] = X2;
+    for (long long o = o0; o < o1; ++o) {
+      const double2 z = xy[o];
+      cost += obs_cost(X0, X1, X2, s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
+    }
+  }
+  const double t = block_sum(cost, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// residual-only pass at a given state (initial cost, ref :85-87)
+__global__ __launch_bounds__(256) void k_cost(long long nobs, int m, const double *__restrict__ cam15,
+                                              const double *__restrict__ X, const int *__restrict__ obs_pt,
+                                              const int *__restrict__ cam_idx, const double2 *__restrict__ xy,
+                                              double f0, double *__restrict__ partials) {
+  extern __shared__ double s_cam[];
+  __shared__ double s_red[16];
+  load_cams_to_lds(cam15, m, f0, s_cam);
+  __syncthreads();
+  double cost = 0.0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < nobs; o += stride) {
+    const double *Xa = X + 3 * (size_t)obs_pt[o];
+    const double2 z = xy[o];
+    cost += obs_cost(Xa[0], Xa[1], Xa[2], s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
+  }
+  const double t = block_sum(cost, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials, int n,
+                                                       double *__restrict__ out) {
+  __shared__ double s_red[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
+  const double t = block_sum(v, s_red);
+  if (threadIdx.x == 0) *out = t;
+}
+
+// debug: planes -> canonical [n_obs][2][P]
+__global__ void k_planes_to_rows(long long nobs, int P, const double2 *__restrict__ planes, double *__restrict__ out) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nobs) return;
+  for (int p = 0; p < P; ++p) {
+    const double2 v = planes[(size_t)p * nobs + o];
+    out[(size_t)o * 2 * P + p] = v.x;
+    out[(size_t)o * 2 * P + P + p] = v.y;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+struct mvba_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  long long N = 0, nobs = 0;
+  int m = 0, gauge_axis = 0, D = 0;
+  double f0 = 1.0;
+  // topology
+  long long *d_pt_ptr = nullptr;
+  int *d_cam = nullptr, *d_obs_pt = nullptr;
+  double2 *d_xy = nullptr;
+  int4 *d_csc = nullptr;
+  long long *d_chunk_ptr = nullptr;
+  int nchunks = 1, lseg = 0, nseg = 1;
+  // state: [cur] committed, [1-cur] trial
+  double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
+  int cur = 0;
+  bool have_params = false, linearized = false, have_trial = false;
+  // linearisation
+  double2 *d_e = nullptr, *d_JX = nullptr, *d_JC = nullptr;
+  double *d_PL = nullptr, *d_PB = nullptr;
+  // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_bred = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
+  // cost
+  double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
+  int n_partials = 0, cost_grid = 0;
+  int *d_flag = nullptr, *h_flag = nullptr;
+  // comm
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  double *d_allcost = nullptr, *h_allcost = nullptr;
+  // profiling
+  bool profiling = false;
+  mvba_stats stats{};
+  struct Ev { int kid; hipEvent_t a, b; };
+  std::vector<Ev> pending;
+  std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+const char *kKernelNames[MVBA_K_COUNT] = {"resid_jac", "point_blocks", "point_inv", "schur",
+                                          "allreduce", "solve",        "backsub_cost", "cost"};
+
+struct Timed {
+  mvba_handle *h;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(mvba_handle *h_, int kid_) : h(h_), kid(kid_) {
+    if (!h->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
+      else hipEventCreate(&e);
+      return e;
+    };
+    a = get(); b = get();
+    hipEventRecord(a, h->stream);
+  }
+  ~Timed() {
+    if (!h->profiling) return;
+    hipEventRecord(b, h->stream);
+    h->pending.push_back({kid, a, b});
+  }
+};
+
+void drain_events(mvba_handle *h) {  // call after a stream sync
+  for (auto &p : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      h->stats.ms[p.kid] += ms;
+      h->stats.launches[p.kid] += 1;
+    }
+    h->pool.push_back(p.a);
+    h->pool.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+template <typename T>
+int dmalloc(T **p, size_t n) {
+  MVBA_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+  return MVBA_OK;
+}
+
+int sync_and_drain(mvba_handle *h) {
+  MVBA_HIP(hipStreamSynchronize(h->stream));
+  drain_events(h);
+  return MVBA_OK;
+}
+
+// sum of per-rank costs in rank order (identical on every rank)
+int global_cost(mvba_handle *h, double *E) {
+  if (h->comm) {
+    Timed t(h, MVBA_K_ALLREDUCE);
+    ncclResult_t r = ncclAllGather(h->d_cost, h->d_allcost, 1, ncclDouble, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    MVBA_HIP(hipMemcpyAsync(h->h_allcost, h->d_allcost, sizeof(double) * h->nranks, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    MVBA_HIP(hipMemcpyAsync(h->h_cost, h->d_cost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  MVBA_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int rc = sync_and_drain(h);
+  if (rc) return rc;
+  if (h->comm) {
+    double s = 0.0;
+    for (int i = 0; i < h->nranks; ++i) s += h->h_allcost[i];
+    *E = s;
+  } else {
+    *E = *h->h_cost;
+  }
+  return MVBA_OK;
+}
+
+int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
+  Timed t(h, MVBA_K_COST);
+  const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
+  hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
+                     h->d_cam, h->d_xy, h->f0, h->d_partials);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost);
+  MVBA_HIP(hipGetLastError());
+  return MVBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mvba_version(void) { return "mvba 0.1 (gfx950)"; }
+const char *mvba_last_error(void) { return g_err.c_str(); }
+const char *mvba_kernel_name(int32_t k) { return (k >= 0 && k < MVBA_K_COUNT) ? kKernelNames[k] : ""; }
+
+int mvba_device_count(int32_t *count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(MVBA_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return MVBA_OK;
+}
+
+int mvba_create(const mvba_problem *p, mvba_handle **out) {
+  if (!p || !out) return fail(MVBA_ERR_BADARG, "null argument");
+  if (p->n_points < 0 || p->n_images < 2 || p->n_obs < 0 || !p->pt_ptr || (p->n_obs && (!p->cam_idx || !p->xy)))
+    return fail(MVBA_ERR_BADARG, "bad problem sizes or null arrays (need n_images >= 2)");
+  if (p->gauge_axis != 0 && p->gauge_axis != 1) return fail(MVBA_ERR_BADARG, "gauge_axis must be 0 or 1");
+  if (p->pt_ptr[0] != 0 || p->pt_ptr[p->n_points] != p->n_obs) return fail(MVBA_ERR_BADARG, "pt_ptr does not span n_obs");
+  if (p->n_obs >= (1LL << 31)) return fail(MVBA_ERR_BADARG, "n_obs per handle must be < 2^31");
+  const long long N = p->n_points, nobs = p->n_obs;
+  const int m = p->n_images;
+  // validate + build point-of-observation and the camera-major index
+  std::vector<int> obs_pt(nobs);
+  std::vector<long long> csc_ptr(m + 1, 0);
+  for (long long a = 0; a < N; ++a) {
+    const long long o0 = p->pt_ptr[a], o1 = p->pt_ptr[a + 1];
+    if (o1 < o0) return fail(MVBA_ERR_BADARG, "pt_ptr not monotone");
+    for (long long o = o0; o < o1; ++o) {
+      const int k = p->cam_idx[o];
+      if (k < 0 || k >= m) return fail(MVBA_ERR_BADARG, "cam_idx out of range");
+      if (o > o0 && p->cam_idx[o - 1] >= k) return fail(MVBA_ERR_BADARG, "cam_idx must ascend within a point");
+      obs_pt[o] = (int)a;
+      csc_ptr[k + 1]++;
+    }
+  }
+  for (int k = 0; k < m; ++k) csc_ptr[k + 1] += csc_ptr[k];
+  std::vector<int4> csc(nobs);
+  {
+    std::vector<long long> fill(csc_ptr.begin(), csc_ptr.end() - 1);
+    for (long long a = 0; a < N; ++a)
+      for (long long o = p->pt_ptr[a]; o < p->pt_ptr[a + 1]; ++o)
+        csc[fill[p->cam_idx[o]]++] = make_int4((int)o, (int)a, (int)(p->pt_ptr[a + 1] - o), 0);
+  }
+
+  mvba_handle *h = new mvba_handle();
+  if (p->device >= 0) {
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) { delete h; return fail(MVBA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+  }
+  {
+    hipError_t e = hipGetDevice(&h->device);
+    if (e != hipSuccess) { delete h; return fail(MVBA_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e)); }
+  }
+  h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7;
+
+  // Schur launch geometry: ~3000 blocks, >= 256 camera-list entries per block
+  const long long avg_len = std::max<long long>(1, nobs / m);
+  h->nchunks = (int)std::max<long long>(1, std::min<long long>((3072 + m - 1) / m, avg_len / 256));
+  const size_t lds_cap = 150 * 1024;
+  h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
+  h->nseg = (m + h->lseg - 1) / h->lseg;
+  std::vector<long long> chunk_ptr((size_t)m * (h->nchunks + 1));
+  for (int k = 0; k < m; ++k) {
+    const int4 *b = csc.data() + csc_ptr[k], *e = csc.data() + csc_ptr[k + 1];
+    for (int c = 0; c <= h->nchunks; ++c) {
+      const long long a_lo = (long long)((__int128)N * c / h->nchunks);
+      const int4 *it = std::lower_bound(b, e, a_lo, [](const int4 &r, long long v) { return r.y < v; });
+      chunk_ptr[(size_t)k * (h->nchunks + 1) + c] = it - csc.data();
+    }
+  }
+  h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
+  const int pt_blocks = (int)((N + 255) / 256);
+  h->n_partials = std::max(h->cost_grid, std::max(pt_blocks, 1));
+
+#define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRY(dmalloc(&h->d_pt_ptr, N + 1));
+  TRY(dmalloc(&h->d_cam, nobs));
+  TRY(dmalloc(&h->d_obs_pt, nobs));
+  TRY(dmalloc(&h->d_xy, nobs));
+  TRY(dmalloc(&h->d_csc, nobs));
+  TRY(dmalloc(&h->d_chunk_ptr, chunk_ptr.size()));
+  for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
+  TRY(dmalloc(&h->d_e, nobs));
+  TRY(dmalloc(&h->d_JX, 3 * nobs));
+  TRY(dmalloc(&h->d_JC, 9 * nobs));
+  TRY(dmalloc(&h->d_PL, 9 * N));
+  TRY(dmalloc(&h->d_PB, 10 * N));
+  const size_t n9 = 9 * (size_t)m;
+  TRY(dmalloc(&h->d_Ab, n9 * n9 + n9));
+  TRY(dmalloc(&h->d_Ared, (size_t)h->D * h->D));
+  TRY(dmalloc(&h->d_bred, h->D));
+  TRY(dmalloc(&h->d_dxi, n9));
+  TRY(dmalloc(&h->d_dX, 3 * N));
+  TRY(dmalloc(&h->d_partials, h->n_partials));
+  TRY(dmalloc(&h->d_cost, 1));
+  TRY(dmalloc(&h->d_flag, 1));
+  TRYH(hipHostMalloc((void **)&h->h_cost, sizeof(double)));
+  TRYH(hipHostMalloc((void **)&h->h_flag, sizeof(int)));
+  TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
+  if (nobs) {
+    TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
+    TRYH(hipMemcpy(h->d_obs_pt, obs_pt.data(), sizeof(int) * nobs, hipMemcpyHostToDevice));
+    TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
+    TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
+  }
+  TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
+  TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
+  // opt in to large dynamic LDS
+  const int strip_lds = (int)((81 * (size_t)h->lseg + 9) * sizeof(double));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
+  TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->D * sizeof(double))));
+#undef TRY
+#undef TRYH
+  *out = h;
+  return MVBA_OK;
+}
+
+void mvba_destroy(mvba_handle *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->comm) ncclCommDestroy(h->comm);
+  void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
+                  h->d_cam15[0], h->d_cam15[1], h->d_e, h->d_JX, h->d_JC, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared,
+                  h->d_bred, h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
+  for (void *q : ptrs) if (q) hipFree(q);
+  if (h->h_cost) hipHostFree(h->h_cost);
+  if (h->h_flag) hipHostFree(h->h_flag);
+  if (h->h_allcost) hipHostFree(h->h_allcost);
+  for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : h->pool) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mvba_set_params(mvba_handle *h, const double *X, const double *f, const double *u, const double *t, const double *R) {
+  if (!h || !X || !f || !u || !t || !R) return fail(MVBA_ERR_BADARG, "null argument");
+  MVBA_HIP(hipSetDevice(h->device));
+  std::vector<double> cam((size_t)h->m * CAM_IN);
+  for (int k = 0; k < h->m; ++k) {
+    double *c = cam.data() + (size_t)k * CAM_IN;
+    c[0] = f[k]; c[1] = u[2 * k]; c[2] = u[2 * k + 1];
+    for (int i = 0; i < 3; ++i) c[3 + i] = t[3 * k + i];
+    for (int i = 0; i < 9; ++i) c[6 + i] = R[9 * k + i];
+  }
+  MVBA_HIP(hipMemcpyAsync(h->d_X[h->cur], X, sizeof(double) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
+  MVBA_HIP(hipMemcpyAsync(h->d_cam15[h->cur], cam.data(), sizeof(double) * cam.size(), hipMemcpyHostToDevice, h->stream));
+  MVBA_HIP(hipStreamSynchronize(h->stream));
+  h->have_params = true; h->linearized = false; h->have_trial = false;
+  return MVBA_OK;
+}
+
+int mvba_get_params(mvba_handle *h, double *X, double *f, double *u, double *t, double *R) {
+  if (!h || !X || !f || !u || !t || !R) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
+  MVBA_HIP(hipSetDevice(h->device));
+  std::vector<double> cam((size_t)h->m * CAM_IN);
+  MVBA_HIP(hipMemcpyAsync(X, h->d_X[h->cur], sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost, h->stream));
+  MVBA_HIP(hipMemcpyAsync(cam.data(), h->d_cam15[h->cur], sizeof(double) * cam.size(), hipMemcpyDeviceToHost, h->stream));
+  MVBA_HIP(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < h->m; ++k) {
+    const double *c = cam.data() + (size_t)k * CAM_IN;
+    f[k] = c[0]; u[2 * k] = c[1]; u[2 * k + 1] = c[2];
+    for (int i = 0; i < 3; ++i) t[3 * k + i] = c[3 + i];
+    for (int i = 0; i < 9; ++i) R[9 * k + i] = c[6 + i];
+  }
+  return MVBA_OK;
+}
+
+int mvba_cost(mvba_handle *h, double *E) {
+  if (!h || !E) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
+  MVBA_HIP(hipSetDevice(h->device));
+  int rc = launch_cost(h, h->d_cam15[h->cur], h->d_X[h->cur]);
+  if (rc) return rc;
+  return global_cost(h, E);
+}
+
+int mvba_linearize(mvba_handle *h) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
+  if (h->nobs) {
+    Timed t(h, MVBA_K_RESID_JAC);
+    const int grid = (int)std::min<long long>(2048, (h->nobs + 255) / 256);
+    hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(256), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
+                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_e, h->d_JX, h->d_JC);
+  }
+  if (h->N) {
+    Timed t(h, MVBA_K_POINT_BLOCKS);
+    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nobs,
+                       h->d_pt_ptr, h->d_e, h->d_JX, h->d_PL);
+  }
+  MVBA_HIP(hipGetLastError());
+  h->linearized = true; h->have_trial = false;
+  h->stats.n_linearize++;
+  return MVBA_OK;
+}
+
+int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
+  if (!h || !E_trial) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->linearized) return fail(MVBA_ERR_STATE, "try_step before linearize");
+  MVBA_HIP(hipSetDevice(h->device));
+  const int m = h->m, D = h->D;
+  const size_t n9 = 9 * (size_t)m;
+  double *d_A = h->d_Ab, *d_b = h->d_Ab + n9 * n9;
+  MVBA_HIP(hipMemsetAsync(h->d_Ab, 0, sizeof(double) * (n9 * n9 + n9), h->stream));
+  if (h->N) {
+    Timed t(h, MVBA_K_POINT_INV);
+    hipLaunchKernelGGL(k_point_inv, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, c, h->d_PL,
+                       h->d_PB, h->d_flag);
+  }
+  if (h->nobs) {
+    Timed t(h, MVBA_K_SCHUR);
+    const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
+    hipLaunchKernelGGL(k_schur_strip, dim3(m, h->nchunks, h->nseg), dim3(1024), lds, h->stream, m, h->nchunks, h->lseg,
+                       h->nobs, h->d_chunk_ptr, h->d_csc, h->d_cam, h->d_e, h->d_JX, h->d_JC, h->d_PB, c, d_A, d_b);
+  }
+  MVBA_HIP(hipGetLastError());
+  if (h->comm) {
+    Timed t(h, MVBA_K_ALLREDUCE);
+    ncclResult_t r = ncclAllReduce(h->d_Ab, h->d_Ab, n9 * n9 + n9, ncclDouble, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  }
+  {
+    Timed t(h, MVBA_K_SOLVE);
+    hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D), dim3(256), 0, h->stream, D, m, h->gauge_axis, d_A, d_b,
+                       h->d_Ared, h->d_bred);
+    for (int j0 = 0; j0 < D; j0 += NB) {
+      const int nb = std::min(NB, D - j0);
+      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb, h->d_flag);
+      const int rem = D - j0 - nb;
+      if (rem > 0) {
+        const int nt = (rem + NB - 1) / NB;
+        hipLaunchKernelGGL(k_chol_panel, dim3(nt), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb);
+        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb);
+      }
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), D * sizeof(double), h->stream, h->d_Ared, D, h->d_bred, m,
+                       h->gauge_axis, h->d_dxi);
+  }
+  MVBA_HIP(hipGetLastError());
+  const int trial = 1 - h->cur;
+  {
+    Timed t(h, MVBA_K_BACKSUB_COST);
+    hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
+                       h->d_cam15[trial]);
+    const int nblk = (int)((h->N + 255) / 256);
+    if (nblk) {
+      const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
+      hipLaunchKernelGGL(k_backsub_cost, dim3(nblk), dim3(256), lds, h->stream, h->N, h->nobs, m, h->d_pt_ptr, h->d_cam,
+                         h->d_xy, h->d_JX, h->d_JC, h->d_PB, h->d_dxi, h->d_X[h->cur], h->d_cam15[trial], h->f0,
+                         h->d_X[trial], h->d_dX, h->d_partials);
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost);
+  }
+  MVBA_HIP(hipGetLastError());
+  h->stats.n_try_step++;
+  int rc = global_cost(h, E_trial);
+  if (rc) return rc;
+  if (*h->h_flag) {
+    const int fl = *h->h_flag;
+    hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
+    return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system not positive definite)");
+  }
+  h->have_trial = true;
+  return MVBA_OK;
+}
+
+int mvba_commit(mvba_handle *h) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  if (!h->have_trial) return fail(MVBA_ERR_STATE, "commit without a trial step");
+  h->cur = 1 - h->cur;
+  h->have_trial = false; h->linearized = false;
+  h->stats.n_commit++;
+  return MVBA_OK;
+}
+
+int mvba_set_profiling(mvba_handle *h, int32_t enabled) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  h->profiling = enabled != 0;
+  return MVBA_OK;
+}
+
+int mvba_get_stats(mvba_handle *h, mvba_stats *out) {
+  if (!h || !out) return fail(MVBA_ERR_BADARG, "null argument");
+  MVBA_HIP(hipSetDevice(h->device));
+  int rc = sync_and_drain(h);
+  if (rc) return rc;
+  *out = h->stats;
+  return MVBA_OK;
+}
+
+int mvba_reset_stats(mvba_handle *h) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  MVBA_HIP(hipSetDevice(h->device));
+  int rc = sync_and_drain(h);
+  if (rc) return rc;
+  h->stats = mvba_stats{};
+  return MVBA_OK;
+}
+
+int mvba_comm_unique_id(void *id128) {
+  if (!id128) return fail(MVBA_ERR_BADARG, "null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  memcpy(id128, &id, 128);
+  return MVBA_OK;
+}
+
+int mvba_comm_init(mvba_handle *h, const void *id128, int32_t rank, int32_t n_ranks) {
+  if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MVBA_ERR_BADARG, "bad comm arguments");
+  MVBA_HIP(hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&h->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  h->rank = rank; h->nranks = n_ranks;
+  int rc = dmalloc(&h->d_allcost, n_ranks);
+  if (rc) return rc;
+  MVBA_HIP(hipHostMalloc((void **)&h->h_allcost, sizeof(double) * n_ranks));
+  return MVBA_OK;
+}
+
+int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity, int64_t *n) {
+  if (!h || !n) return fail(MVBA_ERR_BADARG, "null argument");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t n9 = 9 * (size_t)h->m;
+  long long cnt = 0;
+  switch (which) {
+    case MVBA_BUF_RESIDUAL: cnt = 2 * h->nobs; break;
+    case MVBA_BUF_JX: cnt = 6 * h->nobs; break;
+    case MVBA_BUF_JC: cnt = 18 * h->nobs; break;
+    case MVBA_BUF_E: cnt = 6 * h->N; break;
+    case MVBA_BUF_DP: cnt = 3 * h->N; break;
+    case MVBA_BUF_A_FULL: cnt = n9 * n9; break;
+    case MVBA_BUF_B_FULL: cnt = n9; break;
+    case MVBA_BUF_DXI: cnt = n9; break;
+    case MVBA_BUF_DX: case MVBA_BUF_TRIAL_X: cnt = 3 * h->N; break;
+    case MVBA_BUF_TRIAL_CAM: cnt = (long long)CAM_IN * h->m; break;
+    default: return fail(MVBA_ERR_BADARG, "unknown buffer id");
+  }
+  *n = cnt;
+  if (!out) return MVBA_OK;
+  if (capacity < cnt) return fail(MVBA_ERR_BADARG, "output buffer too small");
+  MVBA_HIP(hipStreamSynchronize(h->stream));
+  auto d2h = [&](const void *src, size_t bytes) { return hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost); };
+  if (which == MVBA_BUF_RESIDUAL || which == MVBA_BUF_JX || which == MVBA_BUF_JC) {
+    const int P = which == MVBA_BUF_RESIDUAL ? 1 : (which == MVBA_BUF_JX ? 3 : 9);
+    const double2 *src = which == MVBA_BUF_RESIDUAL ? h->d_e : (which == MVBA_BUF_JX ? h->d_JX : h->d_JC);
+    double *tmp = nullptr;
+    MVBA_HIP(hipMalloc((void **)&tmp, sizeof(double) * std::max<long long>(cnt, 1)));
+    if (h->nobs)
+      hipLaunchKernelGGL(k_planes_to_rows, dim3((unsigned)((h->nobs + 255) / 256)), dim3(256), 0, h->stream, h->nobs, P, src, tmp);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = d2h(tmp, sizeof(double) * cnt);
+    hipFree(tmp);
+    MVBA_HIP(e);
+  } else if (which == MVBA_BUF_E || which == MVBA_BUF_DP) {
+    std::vector<double> pl(9 * (size_t)h->N);
+    MVBA_HIP(hipMemcpy(pl.data(), h->d_PL, sizeof(double) * pl.size(), hipMemcpyDeviceToHost));
+    for (long long a = 0; a < h->N; ++a) {
+      if (which == MVBA_BUF_E) for (int i = 0; i < 6; ++i) out[6 * a + i] = pl[9 * a + i];
+      else for (int i = 0; i < 3; ++i) out[3 * a + i] = pl[9 * a + 6 + i];
+    }
+  } else if (which == MVBA_BUF_A_FULL) {
+    MVBA_HIP(d2h(h->d_Ab, sizeof(double) * cnt));
+    for (size_t r = 0; r < n9; ++r)  // mirror the populated upper block triangle
+      for (size_t cc = r + 1; cc < n9; ++cc)
+        if (r / 9 != cc / 9) out[cc * n9 + r] = out[r * n9 + cc];
+  } else if (which == MVBA_BUF_B_FULL) {
+    MVBA_HIP(d2h(h->d_Ab + n9 * n9, sizeof(double) * cnt));
+  } else if (which == MVBA_BUF_DXI) {
+    MVBA_HIP(d2h(h->d_dxi, sizeof(double) * cnt));
+  } else if (which == MVBA_BUF_DX) {
+    MVBA_HIP(d2h(h->d_dX, sizeof(double) * cnt));
+  } else if (which == MVBA_BUF_TRIAL_X) {
+    MVBA_HIP(d2h(h->d_X[1 - h->cur], sizeof(double) * cnt));
+  } else if (which == MVBA_BUF_TRIAL_CAM) {
+    MVBA_HIP(d2h(h->d_cam15[1 - h->cur], sizeof(double) * cnt));
+  }
+  return MVBA_OK;
+}
+
+int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2, double f0, double *out26) {
+  if (!X3 || !cam15 || !xy2 || !out26) return fail(MVBA_ERR_BADARG, "null argument");
+  double c[CAM_LDS];
+  expand_cam(cam15, f0, c);
+  ObsJ J;
+  obs_math(X3[0], X3[1], X3[2], c, xy2[0], xy2[1], f0, J);
+  out26[0] = J.e0; out26[1] = J.e1;
+  for (int r = 0; r < 2; ++r) for (int i = 0; i < 3; ++i) out26[2 + 3 * r + i] = J.jx[r][i];
+  for (int r = 0; r < 2; ++r) for (int i = 0; i < 9; ++i) out26[8 + 9 * r + i] = J.jc[r][i];
+  return MVBA_OK;
+}
+
+}  // extern "C"

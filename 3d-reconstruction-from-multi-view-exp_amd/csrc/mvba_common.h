@@ -1,0 +1,112 @@
+// Shared helpers for libmvba.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mvba.h"
+
+namespace mvba {
+
+extern thread_local std::string g_err;
+inline int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define MVBA_HIP(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::mvba::fail(MVBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+// Per-camera record as the kernels keep it in LDS.  19 doubles = 38 dwords: an
+// odd multiple of 2 dwords, so lanes reading the same field of 32 different
+// cameras with ds_read_b64 hit 32 different bank pairs.
+constexpr int CAM_IN = 15;   // f,u,v,t[3],R[9]  (HBM layout, [m][15])
+constexpr int CAM_LDS = 19;  // + 1/f, u/f0, v/f0
+
+struct ObsJ {
+  double e0, e1;
+  double jx[2][3];
+  double jc[2][9];
+};
+
+// Residual and Jacobian rows of one observation.  Follows the reference's
+// operation order where it matters for rounding:
+//   p,q,r                    lib/bundle_adjustment.py:302-305
+//   dp/df = (p - u/f0*r)/f   :336-337      dp/du = r/f0   :350-355
+//   dp/dt = -(f r1 + u r3)   :368-376      d/domega = (-d/dt) x (X - t)   :391-396
+//   rows (r d(p|q) - (p|q) dr) / r^2       :450-467, :492-509
+// c = pointer to a CAM_LDS record (f,u,v,t[3],R[9] row-major with columns = axes,
+// 1/f, u/f0, v/f0).
+__host__ __device__ __forceinline__ void obs_math(double X0, double X1, double X2, const double *c,
+                                                  double x, double y, double f0, ObsJ &J) {
+  const double f = c[0], u = c[1], v = c[2];
+  const double d0 = X0 - c[3], d1 = X1 - c[4], d2 = X2 - c[5];
+  const double *R = c + 6;
+  const double c1 = R[0] * d0 + R[3] * d1 + R[6] * d2;
+  const double c2 = R[1] * d0 + R[4] * d1 + R[7] * d2;
+  const double c3 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+  const double p = f * c1 + u * c3, q = f * c2 + v * c3, r = f0 * c3;
+  J.e0 = p / r - x / f0;
+  J.e1 = q / r - y / f0;
+  const double inv_r2 = 1.0 / (r * r);
+  double ap[3], aq[3], ar[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ap[i] = f * R[3 * i + 0] + u * R[3 * i + 2];
+    aq[i] = f * R[3 * i + 1] + v * R[3 * i + 2];
+    ar[i] = f0 * R[3 * i + 2];
+    J.jx[0][i] = (r * ap[i] - p * ar[i]) * inv_r2;
+    J.jx[1][i] = (r * aq[i] - q * ar[i]) * inv_r2;
+    J.jc[0][3 + i] = -J.jx[0][i];
+    J.jc[1][3 + i] = -J.jx[1][i];
+  }
+  const double dpdf = (p - c[16] * r) * c[15];
+  const double dqdf = (q - c[17] * r) * c[15];
+  J.jc[0][0] = (r * dpdf) * inv_r2;
+  J.jc[1][0] = (r * dqdf) * inv_r2;
+  const double rf0 = r / f0;
+  J.jc[0][1] = (r * rf0) * inv_r2;
+  J.jc[1][1] = 0.0;
+  J.jc[0][2] = 0.0;
+  J.jc[1][2] = (r * rf0) * inv_r2;
+  const double d[3] = {d0, d1, d2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    const double wp = ap[i1] * d[i2] - ap[i2] * d[i1];
+    const double wq = aq[i1] * d[i2] - aq[i2] * d[i1];
+    const double wr = ar[i1] * d[i2] - ar[i2] * d[i1];
+    J.jc[0][6 + i] = (r * wp - p * wr) * inv_r2;
+    J.jc[1][6 + i] = (r * wq - q * wr) * inv_r2;
+  }
+}
+
+// Residual only (trial cost, ref :666-677).
+__host__ __device__ __forceinline__ double obs_cost(double X0, double X1, double X2, const double *c,
+                                                    double x, double y, double f0) {
+  const double d0 = X0 - c[3], d1 = X1 - c[4], d2 = X2 - c[5];
+  const double *R = c + 6;
+  const double c1 = R[0] * d0 + R[3] * d1 + R[6] * d2;
+  const double c2 = R[1] * d0 + R[4] * d1 + R[7] * d2;
+  const double c3 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+  const double p = c[0] * c1 + c[1] * c3, q = c[0] * c2 + c[2] * c3, r = f0 * c3;
+  const double e0 = p / r - x / f0, e1 = q / r - y / f0;
+  return e0 * e0 + e1 * e1;
+}
+
+__host__ __device__ __forceinline__ void expand_cam(const double *in15, double f0, double *out19) {
+#pragma unroll
+  for (int i = 0; i < CAM_IN; ++i) out19[i] = in15[i];
+  out19[15] = 1.0 / in15[0];
+  out19[16] = in15[1] / f0;
+  out19[17] = in15[2] / f0;
+  out19[18] = 0.0;
+}
+
+}  // namespace mvba

@@ -1,0 +1,207 @@
+"""ctypes binding of libmvba.so (include/mvba.h) -- the only way into the HIP engine.
+
+There is NO CPU fallback here: if the library is missing, or there is no GPU,
+construction raises.  (The NumPy restatement lives in ``oracle/`` and is test
+infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MVBA_LIBRARY", os.path.join(os.path.dirname(_HERE), "libmvba.so"))
+
+MVBA_OK, MVBA_ERR_BADARG, MVBA_ERR_SINGULAR, MVBA_ERR_HIP, MVBA_ERR_RCCL, MVBA_ERR_STATE = range(6)
+
+KERNEL_IDS = ("resid_jac", "point_blocks", "point_inv", "schur", "allreduce", "solve", "backsub_cost", "cost")
+BUF = {"residual": 0, "JX": 1, "JC": 2, "E": 3, "dP": 4, "A_full": 5, "b_full": 6, "dxi": 7, "dX": 8,
+       "trial_X": 9, "trial_cam": 10}
+
+_dp = C.POINTER(C.c_double)
+
+
+class Problem(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("n_obs", C.c_int64), ("n_images", C.c_int32),
+                ("gauge_axis", C.c_int32), ("pt_ptr", C.POINTER(C.c_int64)),
+                ("cam_idx", C.POINTER(C.c_int32)), ("xy", _dp), ("f0", C.c_double),
+                ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms", C.c_double * 16), ("launches", C.c_int64 * 16),
+                ("n_linearize", C.c_int64), ("n_try_step", C.c_int64), ("n_commit", C.c_int64)]
+
+
+# every symbol include/mvba.h declares: (restype, argtypes)
+SIGNATURES = {
+    "mvba_version": (C.c_char_p, []),
+    "mvba_last_error": (C.c_char_p, []),
+    "mvba_kernel_name": (C.c_char_p, [C.c_int32]),
+    "mvba_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "mvba_create": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p)]),
+    "mvba_destroy": (None, [C.c_void_p]),
+    "mvba_set_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "mvba_get_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "mvba_cost": (C.c_int, [C.c_void_p, _dp]),
+    "mvba_linearize": (C.c_int, [C.c_void_p]),
+    "mvba_try_step": (C.c_int, [C.c_void_p, C.c_double, _dp]),
+    "mvba_commit": (C.c_int, [C.c_void_p]),
+    "mvba_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mvba_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "mvba_reset_stats": (C.c_int, [C.c_void_p]),
+    "mvba_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mvba_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mvba_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]),
+    "mvba_host_obs_math": (C.c_int, [_dp, _dp, _dp, C.c_double, _dp]),
+    "mvsvd_factorize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmvba.so (loudly) and attach the prototypes."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libmvba.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or make -C 3d-reconstruction-from-multi-view-exp_amd/csrc). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _as(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def raise_for(rc, lib=None):
+    if rc == MVBA_OK:
+        return
+    msg = (lib or load_library()).mvba_last_error().decode()
+    if rc == MVBA_ERR_SINGULAR:
+        raise np.linalg.LinAlgError(msg)  # ref :128 / :146 raise numpy.linalg.LinAlgError
+    if rc == MVBA_ERR_BADARG:
+        raise ValueError(msg)  # ref :27-28
+    raise RuntimeError(f"libmvba error {rc}: {msg}")
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int32(0)
+    rc = lib.mvba_device_count(C.byref(n))
+    return n.value if rc == MVBA_OK else 0
+
+
+class HipEngine:
+    """Device-resident BA state + kernels.  Protocol (shared with the oracle's
+    engine): set_params / get_params / cost / linearize / try_step / commit."""
+
+    def __init__(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, device=-1):
+        from .bundle_adjustment import AXES  # local import: avoid a cycle
+
+        if axis not in AXES:
+            raise ValueError()
+        self.lib = load_library()
+        if device_count() < 1:
+            raise RuntimeError("libmvba: no HIP device visible; the BA engine has no CPU fallback")
+        self.n, self.m = int(n_points), int(n_images)
+        self._pt_ptr = _as(pt_ptr, np.int64)
+        self._cam = _as(cam_idx, np.int32)
+        self._xy = _as(xy, np.float64).reshape(-1, 2)
+        self.n_obs = int(self._cam.shape[0])
+        prob = Problem(self.n, self.n_obs, self.m, AXES[axis],
+                       self._pt_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                       self._cam.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(self._xy), float(f0), int(device), 0)
+        h = C.c_void_p()
+        raise_for(self.lib.mvba_create(C.byref(prob), C.byref(h)), self.lib)
+        self._h = h
+        self.n_solves = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mvba_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_params(self, X, f, u, t, R):
+        X, f, u, t, R = (_as(v, np.float64) for v in (X, f, u, t, R))
+        assert X.shape == (self.n, 3) and f.shape == (self.m,) and u.shape == (self.m, 2)
+        assert t.shape == (self.m, 3) and R.shape == (self.m, 3, 3)
+        raise_for(self.lib.mvba_set_params(self._h, _ptr(X), _ptr(f), _ptr(u), _ptr(t), _ptr(R)), self.lib)
+
+    def get_params(self):
+        X = np.empty((self.n, 3)); f = np.empty(self.m); u = np.empty((self.m, 2))
+        t = np.empty((self.m, 3)); R = np.empty((self.m, 3, 3))
+        raise_for(self.lib.mvba_get_params(self._h, _ptr(X), _ptr(f), _ptr(u), _ptr(t), _ptr(R)), self.lib)
+        return X, f, u, t, R
+
+    def cost(self):
+        E = C.c_double()
+        raise_for(self.lib.mvba_cost(self._h, C.byref(E)), self.lib)
+        return E.value
+
+    def linearize(self):
+        raise_for(self.lib.mvba_linearize(self._h), self.lib)
+
+    def try_step(self, c):
+        E = C.c_double()
+        raise_for(self.lib.mvba_try_step(self._h, float(c), C.byref(E)), self.lib)
+        self.n_solves += 1
+        return E.value
+
+    def commit(self):
+        raise_for(self.lib.mvba_commit(self._h), self.lib)
+
+    # -- measurement / multi-GPU / test hooks
+    def set_profiling(self, on):
+        raise_for(self.lib.mvba_set_profiling(self._h, int(bool(on))), self.lib)
+
+    def reset_stats(self):
+        raise_for(self.lib.mvba_reset_stats(self._h), self.lib)
+
+    def stats(self):
+        s = Stats()
+        raise_for(self.lib.mvba_get_stats(self._h, C.byref(s)), self.lib)
+        out = {k: {"ms": s.ms[i], "launches": s.launches[i]} for i, k in enumerate(KERNEL_IDS)}
+        out["counts"] = {"linearize": s.n_linearize, "try_step": s.n_try_step, "commit": s.n_commit}
+        return out
+
+    def comm_init(self, id128: bytes, rank: int, n_ranks: int):
+        buf = C.create_string_buffer(bytes(id128), 128)
+        raise_for(self.lib.mvba_comm_init(self._h, buf, int(rank), int(n_ranks)), self.lib)
+
+    def debug_read(self, name):
+        n = C.c_int64()
+        raise_for(self.lib.mvba_debug_read(self._h, BUF[name], None, 0, C.byref(n)), self.lib)
+        out = np.empty(n.value)
+        raise_for(self.lib.mvba_debug_read(self._h, BUF[name], _ptr(out), n.value, C.byref(n)), self.lib)
+        return out
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    raise_for(lib.mvba_comm_unique_id(buf), lib)
+    return buf.raw
+
+
+def host_obs_math(X3, cam15, xy2, f0):
+    lib = load_library()
+    out = np.empty(26)
+    X3, cam15, xy2 = _as(X3, np.float64), _as(cam15, np.float64), _as(xy2, np.float64)
+    raise_for(lib.mvba_host_obs_math(_ptr(X3), _ptr(cam15), _ptr(xy2), float(f0), _ptr(out)), lib)
+    return out[:2], out[2:8].reshape(2, 3), out[8:].reshape(2, 9)

@@ -1,0 +1,168 @@
+"""Bundle adjustment with the call surface of the reference's
+``lib/bundle_adjustment.py`` (class ``BundleAdjuster``: constructor :11-21,
+``optimize`` :77-83/:202, ``get_log`` :204-206) on the MI355X engine.
+
+What stays in Python, exactly as the reference does it:
+  * the scene normalisation / de-normalisation with its sign quirk (:208-258),
+  * ``f <- K[:,0,0]``, ``u <- K[:,:2,2]`` (K[1,1], K[2,2] ignored, :45-48),
+  * the Levenberg-Marquardt control flow: c0 = 1e-4, reject iff ``E_ > E``
+    (strict), ``c *= s`` / ``c /= s``, stop on ``|dE| <= tol`` or ``max_iter``,
+    the per-iteration print and the debug log (:100-195).
+Everything numerical per observation / point / reduced system runs in
+``libmvba.so`` (hand-written HIP, see csrc/mvba.hip) through ``_mvba.HipEngine``.
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import numpy.typing as npt
+
+AXES = {"x-right_z-forward": 0, "x-up_z-forward": 1}
+
+
+def dense_to_observations(x: npt.NDArray, visibility_index: npt.NDArray | None):
+    """Dense ``x (N,m,2)`` + bool mask (ref :37, :56-60) -> CSR-by-point list.
+    Invisible entries are dropped instead of multiplied by 0."""
+    n, m = x.shape[:2]
+    vis = np.ones((n, m), dtype=np.bool_) if visibility_index is None else np.asarray(visibility_index, dtype=np.bool_)
+    pt, cam = np.nonzero(vis)
+    pt_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(vis.sum(axis=1), out=pt_ptr[1:])
+    xy = np.ascontiguousarray(np.asarray(x)[pt, cam], dtype=np.float64)
+    return pt_ptr, cam.astype(np.int32), xy
+
+
+def lm_loop(engine, scale_factor, delta_tol, max_iter, on_state=None, verbose=True):
+    """The reference's outer/inner LM loops (:85-195) over an engine that offers
+    cost / linearize / try_step / commit.  Returns the final cost."""
+    E = engine.cost()
+    if on_state is not None:
+        on_state(E)
+    c = 0.0001
+    count = 0
+    while True:
+        engine.linearize()
+        while True:  # no iteration cap, as the reference
+            E_ = engine.try_step(c)
+            if E_ > E:
+                c *= scale_factor
+            else:
+                break
+        engine.commit()
+        if on_state is not None:
+            on_state(E_)
+        count += 1
+        reprojection_error_delta = np.abs(E_ - E)
+        if verbose:
+            print(f"Iteration {count}: reprojection_error_delta = {reprojection_error_delta}")
+        if reprojection_error_delta <= delta_tol or count >= max_iter:
+            break
+        else:
+            E = E_
+            c /= scale_factor
+    return E_
+
+
+class BundleAdjuster:
+    def __init__(
+        self,
+        x: npt.NDArray,
+        init_X: npt.NDArray,
+        init_K: npt.NDArray,
+        init_R: npt.NDArray,
+        init_t: npt.NDArray,
+        f0: float = 1.0,
+        visibility_index: npt.NDArray | None = None,
+        axis: str = "x-right_z-forward",
+    ):
+        x = np.asarray(x)
+        pt_ptr, cam_idx, xy = dense_to_observations(x, visibility_index)
+        self._setup(x.shape[0], x.shape[1], pt_ptr, cam_idx, xy, init_X, init_K, init_R, init_t, f0, axis)
+
+    @classmethod
+    def from_observations(cls, n_points, n_images, pt_ptr, cam_idx, xy, init_X, init_K, init_R, init_t,
+                          f0: float = 1.0, axis: str = "x-right_z-forward", **engine_kw):
+        """Extension for sizes where the dense (N,m,2) array cannot exist
+        (SURVEY 8f rank 1): observation list in CSR-by-point form."""
+        self = cls.__new__(cls)
+        self._setup(n_points, n_images, pt_ptr, cam_idx, xy, init_X, init_K, init_R, init_t, f0, axis, **engine_kw)
+        return self
+
+    # -- construction ------------------------------------------------------
+    def _make_engine(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, **kw):
+        from ._mvba import HipEngine
+
+        return HipEngine(n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, **kw)
+
+    def _setup(self, n_points, n_images, pt_ptr, cam_idx, xy, init_X, init_K, init_R, init_t, f0, axis, **engine_kw):
+        init_X, init_K = np.asarray(init_X, dtype=np.float64), np.asarray(init_K, dtype=np.float64)
+        init_R, init_t = np.asarray(init_R, dtype=np.float64), np.asarray(init_t, dtype=np.float64)
+        # camera-0 pose and baseline length for the way back (ref :23-33)
+        if axis == "x-right_z-forward":
+            c0c1_len = np.abs(init_R[0, :, 0] @ (init_t[1] - init_t[0]))
+        elif axis == "x-up_z-forward":
+            c0c1_len = np.abs(init_R[0, :, 1] @ (init_t[1] - init_t[0]))
+        else:
+            raise ValueError()
+        self._init_camera0_params = {"R": init_R[0], "t": init_t[0], "c0c1_len": c0c1_len}
+        X, R, t = BundleAdjuster._transform_to_normalize_coodinates(init_X, init_R, init_t, axis=axis)
+        self._f0 = f0
+        self._n_points, self._n_images = int(n_points), int(n_images)
+        self._engine = self._make_engine(self._n_points, self._n_images, pt_ptr, cam_idx, xy, f0, axis, **engine_kw)
+        self._engine.set_params(X, init_K[:, 0, 0], init_K[:, :2, 2], t, R)  # ref :45-48
+        self._log: list[dict[str, npt.NDArray | float]] = []
+
+    # -- the reference's public methods --------------------------------------
+    def optimize(
+        self,
+        scale_factor: float = 10.0,
+        delta_tol: float = 1e-8,
+        max_iter: int = 100,
+        is_debug: bool = False,
+    ) -> tuple[npt.NDArray, npt.NDArray, npt.NDArray, npt.NDArray]:
+        on_state = None
+        if is_debug:
+            self._log.clear()
+
+            def on_state(err):  # log entries are copies, normalised frame (ref :91-97, :175-183)
+                X, _, _, t, R = self._engine.get_params()
+                self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": err})
+
+        lm_loop(self._engine, scale_factor, delta_tol, max_iter, on_state)
+        X, f, u, t, R = self._engine.get_params()
+        X, R, t = BundleAdjuster._inverse_transform_to_global_coordinates(self._init_camera0_params, X, R, t)
+        # the reference rebinds its state to the de-normalised values (:198-200)
+        self._engine.set_params(X, f, u, t, R)
+        return X, self._get_K(f, u), R, t
+
+    def get_log(self) -> list[dict[str, npt.NDArray | float]]:
+        return self._log
+
+    # -- host-side pieces (ref :208-258, :283-289) ---------------------------------
+    @staticmethod
+    def _transform_to_normalize_coodinates(X, R, t, axis: str = "x-right_z-forward"):
+        X_ = X - t[0]
+        t_ = t - t[0]
+        if axis == "x-right_z-forward":
+            j = np.array([np.sign(t_[1, 0]), 0, 0])
+        elif axis == "x-up_z-forward":
+            j = np.array([0, np.sign(t_[1, 1]), 0])
+        else:
+            raise ValueError()
+        # sign from the world frame, magnitude from camera 0's frame (ref :227-234)
+        s = j @ R[0].T @ t_[1][:, np.newaxis]
+        return (X_ @ R[0]) / s, R[0].T @ R, (t_ @ R[0]) / s
+
+    @staticmethod
+    def _inverse_transform_to_global_coordinates(camera0_param: dict[str, Any], X, R, t):
+        R0, t0, scale = camera0_param["R"], camera0_param["t"], camera0_param["c0c1_len"]
+        return (scale * X) @ R0.T + t0, R0 @ R, (scale * t) @ R0.T + t0
+
+    def _get_K(self, f: npt.NDArray, u: npt.NDArray) -> npt.NDArray:
+        K = np.zeros((self._n_images, 3, 3))
+        K[:, (0, 1), (0, 1)] = f[:, np.newaxis]
+        K[:, :2, 2] = u
+        K[:, 2, 2] = self._f0
+        return K

@@ -1,0 +1,145 @@
+/* mvba.h -- C ABI of libmvba.so: MI355X-native bundle adjustment + factorization SVD.
+ *
+ * The reference (takah29/3d-reconstruction-from-multi-view-exp) has no FFI layer;
+ * the surface it defines is Python:
+ *     lib/bundle_adjustment.py:10-206   class BundleAdjuster  (ctor / optimize / get_log)
+ *     lib/factorization.py:5-15         factorization_method(W, n_rank)
+ * This header is what a ctypes binding underneath those two call sites binds
+ * (INTEGRATION.md shows the stub).  The Levenberg-Marquardt control flow
+ * (damping schedule, strict accept test, stop rule, log, print; ref :100-195)
+ * stays in Python so it is bit-for-bit the reference's; everything that touches
+ * observations, points or the reduced camera system is behind these calls.
+ *
+ * Conventions: every pointer is HOST memory, C-contiguous, little-endian;
+ * doubles are IEEE binary64; no struct is passed by value; every function
+ * returns an int status (0 = MVBA_OK) and mvba_last_error() gives the
+ * thread-local message.  A handle is not thread-safe: one host thread per handle.
+ * State (points, cameras) lives in the NORMALISED frame of ref :208-240; the
+ * normalise / denormalise transforms are host-side NumPy in lib/bundle_adjustment.py.
+ */
+#ifndef MVBA_H
+#define MVBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVBA_OK 0
+#define MVBA_ERR_BADARG 1   /* -> ValueError              (ref :27-28, :231-232)              */
+#define MVBA_ERR_SINGULAR 2 /* -> numpy.linalg.LinAlgError (ref :128 batched inv, :146 solve) */
+#define MVBA_ERR_HIP 3      /* -> RuntimeError                                                */
+#define MVBA_ERR_RCCL 4     /* -> RuntimeError                                                */
+#define MVBA_ERR_STATE 5    /* call order violated (e.g. try_step before linearize)           */
+
+typedef struct mvba_handle mvba_handle;
+
+/* Observation list, CSR by point (replaces the dense x (N,m,2) + bool mask of
+ * ref :37, :56-60).  In a point-sharded job n_points / n_obs / pt_ptr describe
+ * THIS rank's points; n_images is global (cameras are replicated). */
+typedef struct mvba_problem {
+  int64_t n_points;       /* points held by this handle                          */
+  int64_t n_obs;          /* = pt_ptr[n_points]                                  */
+  int32_t n_images;       /* cameras (global)                                    */
+  int32_t gauge_axis;     /* 0: "x-right_z-forward" (drops param 12), 1: "x-up_z-forward" (drops 13); ref :62-72 */
+  const int64_t *pt_ptr;  /* [n_points+1] offsets into cam_idx / xy              */
+  const int32_t *cam_idx; /* [n_obs] camera of each observation, ascending within a point */
+  const double *xy;       /* [n_obs][2] observed image coordinates               */
+  double f0;              /* ref :50                                             */
+  int32_t device;         /* HIP device ordinal, -1 = current device             */
+  int32_t reserved;
+} mvba_problem;
+
+/* Kernel ids for mvba_stats (names via mvba_kernel_name). */
+enum {
+  MVBA_K_RESID_JAC = 0, /* K1 residual + 2x3 / 2x9 Jacobians   (ref :291-427)            */
+  MVBA_K_POINT_BLOCKS,  /* K2 E_a, dP_a                         (ref :429-469, :519-556)  */
+  MVBA_K_POINT_INV,     /* K3a damped 3x3 inverse, E^-1 dP      (ref :120-128)            */
+  MVBA_K_SCHUR,         /* K3 A = G^ - sum F^T E^-1 F, b        (ref :132-143, :471-517, :618-664) */
+  MVBA_K_ALLREDUCE,     /* C1 RCCL all-reduce of [A|b]                                    */
+  MVBA_K_SOLVE,         /* K4 gauge strip + dense solve         (ref :146)                */
+  MVBA_K_BACKSUB_COST,  /* K5+K6 dX, trial state, trial cost    (ref :152-162, :260-281, :666-677) */
+  MVBA_K_COST,          /* residual-only cost pass              (ref :85-87)              */
+  MVBA_K_COUNT
+};
+
+typedef struct mvba_stats {
+  double ms[16];        /* accumulated device time per kernel id (hipEvents on the library's stream) */
+  int64_t launches[16]; /* number of timed launches per kernel id                */
+  int64_t n_linearize, n_try_step, n_commit;
+} mvba_stats;
+
+const char *mvba_version(void);
+const char *mvba_last_error(void);
+const char *mvba_kernel_name(int32_t kernel_id);
+int mvba_device_count(int32_t *count);
+
+/* Copies the observation list to the device and builds the camera-major index. */
+int mvba_create(const mvba_problem *problem, mvba_handle **out);
+void mvba_destroy(mvba_handle *h);
+
+/* Committed state, normalised frame: X [n_points][3], f [m], u [m][2], t [m][3],
+ * R [m][3][3] row-major with COLUMNS = camera axes (ref :40-48).               */
+int mvba_set_params(mvba_handle *h, const double *X, const double *f, const double *u,
+                    const double *t, const double *R);
+int mvba_get_params(mvba_handle *h, double *X, double *f, double *u, double *t, double *R);
+
+/* E = sum over observations of |e|^2 at the committed state (ref :666-677). */
+int mvba_cost(mvba_handle *h, double *E);
+/* K1+K2 at the committed state (ref :103-116). */
+int mvba_linearize(mvba_handle *h);
+/* One LM trial with damping c (ref :118-162): K3a,K3,(C1),K4,K5,K6; the trial
+ * state stays on the device.  *E_trial is the job-wide cost at the trial state. */
+int mvba_try_step(mvba_handle *h, double c, double *E_trial);
+/* trial -> committed (ref :169-173). */
+int mvba_commit(mvba_handle *h);
+
+/* Per-kernel device timing; off by default. */
+int mvba_set_profiling(mvba_handle *h, int32_t enabled);
+int mvba_get_stats(mvba_handle *h, mvba_stats *out);
+int mvba_reset_stats(mvba_handle *h);
+
+/* Point-sharded multi-GPU (one process per GPU): rank 0 makes an id, the host
+ * side ships its 128 bytes to the other ranks, every rank calls comm_init.
+ * Afterwards try_step all-reduces the partial reduced system [A|b] over RCCL and
+ * cost / try_step return the sum of the ranks' costs taken in rank order.      */
+int mvba_comm_unique_id(void *id128);
+int mvba_comm_init(mvba_handle *h, const void *id128, int32_t rank, int32_t n_ranks);
+
+/* Test hook: download an intermediate in canonical per-observation / per-point
+ * row-major layout.  Returns the element count in *n (out may be NULL to query). */
+enum {
+  MVBA_BUF_RESIDUAL = 0, /* [n_obs][2]                                       */
+  MVBA_BUF_JX,           /* [n_obs][2][3]                                    */
+  MVBA_BUF_JC,           /* [n_obs][2][9]                                    */
+  MVBA_BUF_E,            /* [n_points][6]  xx,xy,xz,yy,yz,zz  (undamped)     */
+  MVBA_BUF_DP,           /* [n_points][3]                                    */
+  MVBA_BUF_A_FULL,       /* [9m][9m] symmetric, before gauge removal         */
+  MVBA_BUF_B_FULL,       /* [9m]                                             */
+  MVBA_BUF_DXI,          /* [9m] with zeros at the gauge slots               */
+  MVBA_BUF_DX,           /* [n_points][3]                                    */
+  MVBA_BUF_TRIAL_X,      /* [n_points][3]                                    */
+  MVBA_BUF_TRIAL_CAM     /* [m][15]  f,u,v,t[3],R[9]                         */
+};
+int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity, int64_t *n);
+
+/* Host-only check of the per-observation math the kernels use (no GPU needed):
+ * cam15 = f,u,v,t[3],R[9]; out = e[2], JX[6], JC[18].                          */
+int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2, double f0,
+                       double *out26);
+
+/* ---- factorization (ref lib/factorization.py:5-15) ---------------------------
+ * Wt: the measurement matrix as its callers hold it, row-major [n_rows][n_cols]
+ * with n_rows = points (tall) and n_cols = 2m or 3m; the reference's W is Wt^T
+ * (perspective_camera_calibration.py:533, affine_camera_calibration.py:236).
+ * dtype: 0 = float32, 1 = float64 (outputs have the input dtype, ref quirk B.10).
+ * Outputs: M [n_cols][n_rank] (= U[:, :r]), sigma [min(n_cols,..)] first n_rank
+ * filled, S [n_rank][n_rows] (= diag(sigma) Vt[:r]).  Thin, never forms Vt.    */
+int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype,
+                    int32_t n_rank, void *M, void *sigma, void *S, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVBA_H */
