@@ -1,0 +1,75 @@
+"""Point-sharded multi-GPU bundle adjustment: one process per GPU.
+
+Points are independent given the cameras, so each rank owns a contiguous range
+of point ids (balanced by observation count), a replica of the camera
+parameters, and its slice of the observation list.  The only data-path exchange
+is ONE all-reduce of the packed reduced camera system ``[A | b]`` per LM solve,
+done inside ``libmvba.so`` with RCCL on the engine's own stream
+(``mvba_comm_init``); trial costs are all-gathered (1 double per rank) and summed
+in rank order so every rank takes the identical accept/reject decision.
+
+``torch.distributed`` is used here only to bootstrap (ship RCCL's 128-byte
+unique id) and by callers for barriers/timing - never on the data path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition_points(pt_ptr: np.ndarray, n_parts: int) -> list[tuple[int, int]]:
+    """Contiguous point ranges with ~equal observation counts (CSR prefix sums)."""
+    pt_ptr = np.asarray(pt_ptr, dtype=np.int64)
+    n = len(pt_ptr) - 1
+    total = int(pt_ptr[-1])
+    cuts = [0]
+    for r in range(1, n_parts):
+        target = total * r // n_parts
+        a = int(np.searchsorted(pt_ptr, target, side="left"))
+        cuts.append(min(max(a, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(n_parts)]
+
+
+def slice_observations(pt_ptr, cam_idx, xy, lo, hi):
+    """The CSR slice for points [lo, hi)."""
+    o0, o1 = int(pt_ptr[lo]), int(pt_ptr[hi])
+    return (np.asarray(pt_ptr[lo:hi + 1], dtype=np.int64) - o0, np.asarray(cam_idx[o0:o1]), np.asarray(xy[o0:o1]))
+
+
+def broadcast_bytes(payload: bytes | None, n: int, src: int = 0, group=None) -> bytes:
+    """Ship ``n`` bytes from ``src`` to every rank over torch.distributed (any backend)."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf = torch.zeros(n, dtype=torch.uint8, device=dev)
+    if dist.get_rank(group) == src:
+        buf.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(buf, src=src, group=group)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def attach_rccl(engine, group=None):
+    """Give a HipEngine its RCCL communicator (collective: call on every rank)."""
+    import torch.distributed as dist
+
+    from . import _mvba
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = _mvba.comm_unique_id() if rank == 0 else None
+    uid = broadcast_bytes(uid, 128, 0, group)
+    engine.comm_init(uid, rank, world)
+    return rank, world
+
+
+def numpy_allreduce(group=None):
+    """In-place float64 sum over ranks for host arrays (gloo); used to drive the
+    CPU oracle engine through the same sharding logic in tests."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(a: np.ndarray):
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    return allreduce

@@ -34,34 +34,52 @@ def dense_to_observations(x: npt.NDArray, visibility_index: npt.NDArray | None):
     return pt_ptr, cam.astype(np.int32), xy
 
 
-def lm_loop(engine, scale_factor, delta_tol, max_iter, on_state=None, verbose=True):
-    """The reference's outer/inner LM loops (:85-195) over an engine that offers
-    cost / linearize / try_step / commit.  Returns the final cost."""
-    E = engine.cost()
-    if on_state is not None:
-        on_state(E)
-    c = 0.0001
-    count = 0
-    while True:
-        engine.linearize()
+class LevenbergMarquardt:
+    """The reference's LM control state (:85-101, :118-195) over an engine that
+    offers cost / linearize / try_step / commit; ``iterate()`` is one outer
+    iteration: linearise once, retry with ``c *= s`` while the trial cost is
+    strictly larger, commit."""
+
+    def __init__(self, engine, scale_factor):
+        self.engine, self.scale_factor = engine, scale_factor
+        self.E = engine.cost()
+        self.c = 0.0001
+        self.count = 0
+
+    def iterate(self):
+        g = self.engine
+        g.linearize()
         while True:  # no iteration cap, as the reference
-            E_ = engine.try_step(c)
-            if E_ > E:
-                c *= scale_factor
+            E_ = g.try_step(self.c)
+            if E_ > self.E:
+                self.c *= self.scale_factor
             else:
                 break
-        engine.commit()
+        g.commit()
+        self.count += 1
+        delta = np.abs(E_ - self.E)
+        return E_, delta
+
+    def carry_on(self, E_):
+        """ref :194-195"""
+        self.E = E_
+        self.c /= self.scale_factor
+
+
+def lm_loop(engine, scale_factor, delta_tol, max_iter, on_state=None, verbose=True):
+    """The reference's outer loop (:102-195).  Returns the final cost."""
+    lm = LevenbergMarquardt(engine, scale_factor)
+    if on_state is not None:
+        on_state(lm.E)
+    while True:
+        E_, reprojection_error_delta = lm.iterate()
         if on_state is not None:
             on_state(E_)
-        count += 1
-        reprojection_error_delta = np.abs(E_ - E)
         if verbose:
-            print(f"Iteration {count}: reprojection_error_delta = {reprojection_error_delta}")
-        if reprojection_error_delta <= delta_tol or count >= max_iter:
+            print(f"Iteration {lm.count}: reprojection_error_delta = {reprojection_error_delta}")
+        if reprojection_error_delta <= delta_tol or lm.count >= max_iter:
             break
-        else:
-            E = E_
-            c /= scale_factor
+        lm.carry_on(E_)
     return E_
 
 

@@ -156,7 +156,7 @@ class OracleEngine:
     point shards - the exchange step of SURVEY §8e."""
 
     def __init__(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, allreduce=None,
-                 pair_chunk=200_000):
+                 pair_chunk=200_000, sparse_schur=True):
         self.n, self.m = int(n_points), int(n_images)
         self.pt_ptr = np.asarray(pt_ptr, np.int64)
         self.cam = np.asarray(cam_idx, np.int64)
@@ -167,6 +167,7 @@ class OracleEngine:
         self.keep = np.setdiff1d(np.arange(9 * self.m), self.removed)
         self.allreduce = allreduce
         self.pair_chunk = pair_chunk
+        self.sparse_schur = sparse_schur
         self.n_solves = 0
 
     # -- parameters
@@ -197,17 +198,12 @@ class OracleEngine:
         self.F = 2.0 * np.einsum("ori,orj->oij", JX, JC)  # (n_obs,3,9)            ref :558-616
         self.G = 2.0 * _segsum(self.cam, np.einsum("ori,orj->oij", JC, JC), self.m)  # (m,9,9) ref :618-664
 
-    # -- reduced camera system for damping c (ref :118-143), FULL 9m x 9m before gauge removal
-    def reduced_system(self, c):
+
+    def _schur_pairs(self, Y):
+        """sum_a F_ak^T E^-1 F_al over all ordered pairs of observations of a point -> (m,m,9,9)."""
         m = self.m
-        Ec = self.E.copy()
-        i3 = np.arange(3)
-        Ec[:, i3, i3] *= 1.0 + c
-        self.Einv = np.linalg.inv(Ec)  # LinAlgError("Singular matrix") on a zero-degree point, as ref :128
-        Y = np.einsum("oij,ojk->oik", self.Einv[self.pt], self.F)  # E^-1 F_ak   (n_obs,3,9)
         A4 = np.zeros((m, m, 9, 9))
         deg = np.diff(self.pt_ptr)
-        # all ordered pairs of observations of the same point, chunked over points
         start = 0
         while start < self.n:
             stop = start
@@ -226,7 +222,27 @@ class OracleEngine:
             blk = np.einsum("pji,pjk->pik", self.F[oi], Y[oj])  # F_ak^T E^-1 F_al
             np.add.at(A4, (self.cam[oi], self.cam[oj]), blk)
             start = stop
-        A = -A4.transpose(0, 2, 1, 3).reshape(9 * m, 9 * m)
+        return A4
+
+    # -- reduced camera system for damping c (ref :118-143), FULL 9m x 9m before gauge removal
+    def reduced_system(self, c):
+        m = self.m
+        Ec = self.E.copy()
+        i3 = np.arange(3)
+        Ec[:, i3, i3] *= 1.0 + c
+        self.Einv = np.linalg.inv(Ec)  # LinAlgError("Singular matrix") on a zero-degree point, as ref :128
+        Y = np.einsum("oij,ojk->oik", self.Einv[self.pt], self.F)  # E^-1 F_ak   (n_obs,3,9)
+        if self.sparse_schur:
+            # S = F^T (E^-1 F) as one block-sparse product (scipy BSR, 3x9 blocks): the
+            # fast CPU form used for the timed cpu_baseline; equals the pair loop below.
+            from scipy.sparse import bsr_matrix
+
+            shape = (3 * self.n, 9 * m)
+            Fs = bsr_matrix((self.F, self.cam, self.pt_ptr), shape=shape)
+            Ys = bsr_matrix((Y, self.cam, self.pt_ptr), shape=shape)
+            A = -np.asarray((Fs.T.tocsr() @ Ys.tocsr()).todense())
+        else:
+            A = -self._schur_pairs(Y).transpose(0, 2, 1, 3).reshape(9 * m, 9 * m)
         bvec = np.einsum("oji,oj->oi", Y, self.dP[self.pt])  # F^T E^-1 dP per obs (9)
         b = _segsum(self.cam, bvec, m) - self.dF
         for k in range(m):
