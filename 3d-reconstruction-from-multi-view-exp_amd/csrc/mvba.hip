@@ -9,14 +9,20 @@
 //   C1  ncclAllReduce    [A|b] across point shards                            
 //   K4  k_chol_* / trsv  dense solve of the gauge-reduced system              (ref :146)
 //   K5+K6 k_backsub_cost dX_a, trial state, trial cost                        (ref :152-162, :260-281, :666-677)
-// HBM layout: observations sorted by point (CSR); every per-observation product
-// is a set of double2 "planes" plane[p][obs] = (row0[p], row1[p]) so that one
-// wave moves 1 KiB per load/store instruction: e (1 plane), J_X (3), J_C (9).
+// HBM layout: observations sorted by point (CSR).  The linearisation of ONE
+// observation is ONE 128-byte line ("record", 8 x double2 = (row0,row1) pairs):
+//   slot 0-2  J_X columns          slot 3    dJ/df
+//   slot 4-6  dJ/domega columns    slot 7    residual e
+// J_C's translation columns are exactly -J_X and its (u,v) columns are the
+// constants (1/f0,0),(0,1/f0) (ref :350-376), so the 2x9 block is implied by the
+// record.  A point's observations are consecutive lines, which is what makes the
+// camera-major Schur gather cheap (one line per (point,camera) pair).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -62,44 +68,69 @@ __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
 }
 
 // ------------------------------------------------------------------ K1
-// One thread per observation, grid-stride; camera table staged once per block.
-// Algorithmic traffic: 24 B in + 208 B out per observation + 24 B per point.
+// One thread per observation, grid-stride over 256-observation tiles; camera table
+// staged once per block.  Each wave transposes its 64 records through LDS so that
+// every global store instruction writes 1 KiB contiguous (8 whole lines).
+// Algorithmic traffic: 24 B in + 128 B out per observation + 24 B per point.
+constexpr int REC = 8;  // double2 slots per observation record (128 B)
+
 __global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
                                                    const double *__restrict__ X,
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
                                                    const double2 *__restrict__ xy, double f0,
-                                                   double2 *__restrict__ e, double2 *__restrict__ JX,
-                                                   double2 *__restrict__ JC) {
-  extern __shared__ double s_cam[];
+                                                   double2 *__restrict__ rec) {
+  extern __shared__ double smem[];
+  double *s_cam = smem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
+  double2 *stage = reinterpret_cast<double2 *>(smem + ((m * CAM_LDS + 1) & ~1)) + wave * (64 * REC);
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < nobs; o += stride) {
-    const int a = obs_pt[o], k = cam_idx[o];
-    const double2 z = xy[o];
-    const double *Xa = X + 3 * (size_t)a;
-    ObsJ J;
-    obs_math(Xa[0], Xa[1], Xa[2], s_cam + k * CAM_LDS, z.x, z.y, f0, J);
-    e[o] = make_double2(J.e0, J.e1);
+  for (long long base = (long long)blockIdx.x * blockDim.x; base < nobs; base += stride) {
+    const long long wbase = base + 64 * wave;  // first observation of this wave's tile
+    const long long o = wbase + lane;
+    if (o < nobs) {
+      const int a = obs_pt[o], k = cam_idx[o];
+      const double2 z = xy[o];
+      const double *Xa = X + 3 * (size_t)a;
+      ObsJ J;
+      obs_math(Xa[0], Xa[1], Xa[2], s_cam + k * CAM_LDS, z.x, z.y, f0, J);
+      // swizzled slot position (s ^ (lane & 7)): conflict-free ds_write_b128
+      double2 *row = stage + lane * REC;
+      const int sw = lane & 7;
+      row[0 ^ sw] = make_double2(J.jx[0][0], J.jx[1][0]);
+      row[1 ^ sw] = make_double2(J.jx[0][1], J.jx[1][1]);
+      row[2 ^ sw] = make_double2(J.jx[0][2], J.jx[1][2]);
+      row[3 ^ sw] = make_double2(J.jc[0][0], J.jc[1][0]);
+      row[4 ^ sw] = make_double2(J.jc[0][6], J.jc[1][6]);
+      row[5 ^ sw] = make_double2(J.jc[0][7], J.jc[1][7]);
+      row[6 ^ sw] = make_double2(J.jc[0][8], J.jc[1][8]);
+      row[7 ^ sw] = make_double2(J.e0, J.e1);
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-synchronous hand-over through LDS (in-order DS queue)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) JX[(size_t)p * nobs + o] = make_double2(J.jx[0][p], J.jx[1][p]);
-#pragma unroll
-    for (int p = 0; p < 9; ++p) JC[(size_t)p * nobs + o] = make_double2(J.jc[0][p], J.jc[1][p]);
+    for (int q = 0; q < REC; ++q) {
+      const int ol = q * 8 + (lane >> 3), pos = lane & 7;  // local observation, stored position
+      const double2 v = stage[ol * REC + pos];
+      const long long og = wbase + ol;
+      if (og < nobs) rec[og * REC + (pos ^ (ol & 7))] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 // ------------------------------------------------------------------ K2
 // One thread per point: E_a (6 unique), dP_a (3).  PL[a][9] = Exx,Exy,Exz,Eyy,Eyz,Ezz,dP0..2
-__global__ __launch_bounds__(256) void k_point_blocks(long long npts, long long nobs,
-                                                      const long long *__restrict__ pt_ptr,
-                                                      const double2 *__restrict__ e,
-                                                      const double2 *__restrict__ JX, double *__restrict__ PL) {
+__global__ __launch_bounds__(256) void k_point_blocks(long long npts, const long long *__restrict__ pt_ptr,
+                                                      const double2 *__restrict__ rec, double *__restrict__ PL) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= npts) return;
   double E[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (long long o = pt_ptr[a]; o < pt_ptr[a + 1]; ++o) {
-    const double2 r = e[o], x0 = JX[o], x1 = JX[nobs + o], x2 = JX[2 * nobs + o];
+    const double2 *q = rec + o * REC;
+    const double2 x0 = q[0], x1 = q[1], x2 = q[2], r = q[7];
     E[0] += x0.x * x0.x + x0.y * x0.y;
     E[1] += x0.x * x1.x + x0.y * x1.y;
     E[2] += x0.x * x2.x + x0.y * x2.y;
@@ -151,11 +182,21 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
 //   -(F_ak^T E^-1 F_al)[i][j] = -Jc_k[:,i] . ( 2 Jx_k E^-1 ( 2 Jx_l^T Jc_l[:,j] ) )
 // The diagonal item (l == k) also adds G^_k (ref :618-664 with :123-125 damping)
 // and the right-hand side 2 Jc_k^T (Jx_k v_a - e_ak)   (ref :138-143, :471-517).
-__global__ __launch_bounds__(1024) void k_schur_strip(
-    int m, int nchunks, int lseg, long long nobs, const long long *__restrict__ chunk_ptr,
-    const int4 *__restrict__ csc, const int *__restrict__ cam_idx, const double2 *__restrict__ e,
-    const double2 *__restrict__ JX, const double2 *__restrict__ JC, const double *__restrict__ PB, double c,
-    double *__restrict__ Afull, double *__restrict__ bfull) {
+// Wave-uniform operands are read through the constant address space so the
+// compiler issues scalar (SMEM) loads into SGPRs instead of 64 identical vector loads.
+#define MVBA_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const T MVBA_CONST_AS *)p;
+#pragma clang diagnostic pop
+}
+
+__global__ __launch_bounds__(1024, 8) void k_schur_strip(
+    int m, int nchunks, int lseg, const long long *__restrict__ chunk_ptr, const int4 *__restrict__ csc,
+    const int *__restrict__ cam_idx, const double2 *__restrict__ rec, const double *__restrict__ PB, double c,
+    double f0, double *__restrict__ Afull, double *__restrict__ bfull) {
   extern __shared__ double strip[];
   const int k = blockIdx.x, chunk = blockIdx.y, seg = blockIdx.z;
   const int l_lo = k + seg * lseg;
@@ -164,64 +205,107 @@ __global__ __launch_bounds__(1024) void k_schur_strip(
   const int W = 9 * (l_hi - l_lo);
   double *sb = strip + 9 * W;
   for (int i = threadIdx.x; i < 9 * W + 9; i += blockDim.x) strip[i] = 0.0;
-  __syncthreads();
+  // Workgroup barrier WITHOUT a compiler-level memory fence: a fencing __syncthreads() here
+  // makes LLVM treat every later load as clobbered and turns the wave-uniform k-side loads
+  // back into 64-lane vector loads (+70 VGPRs).  The LDS writes above are drained first.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::);
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
+  const int nw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slot = lane / 9, j = lane - 9 * slot;
+  // which record slot holds J_C column j, and how to turn it into the column (see file header)
+  const int sel = (j == 0) ? 3 : (j >= 6 ? j - 2 : (j >= 3 ? j - 3 : 0));
+  const double cu = 1.0 / f0;
   const long long beg = chunk_ptr[(size_t)k * (nchunks + 1) + chunk];
   const long long end = chunk_ptr[(size_t)k * (nchunks + 1) + chunk + 1];
   const double damp = 1.0 + c;
+  // scalar views (plain int / double elements: HIP vector types do not cross address spaces)
+  const auto *csc_c = as_const(reinterpret_cast<const int *>(csc));
+  const auto *rec_c = as_const(reinterpret_cast<const double *>(rec));
+  const auto *PBc = as_const(PB);
+  auto load_rec = [&](long long i) { return make_int4(csc_c[4 * i], csc_c[4 * i + 1], csc_c[4 * i + 2], 0); };
 
-  for (long long idx = beg + wave; idx < end; idx += nw) {
-    const int4 rec = csc[idx];  // wave-uniform
-    const int o = rec.x, a = rec.y, nrem = rec.z;
-    double2 jxk[3], jck[9];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) jxk[p] = JX[(size_t)p * nobs + o];
-#pragma unroll
-    for (int p = 0; p < 9; ++p) jck[p] = JC[(size_t)p * nobs + o];
-    const double2 ek = e[o];
-    const double *pb = PB + 10 * (size_t)a;
+  long long idx = beg + wave;
+  int4 cur = make_int4(0, 0, 0, 0);
+  if (idx < end) cur = load_rec(idx);
+  while (idx < end) {
+    const int o = cur.x, a = cur.y, nrem = cur.z;
+    const long long idx_next = idx + nw;
+    if (idx_next < end) cur = load_rec(idx_next);  // prefetch the next camera-list entry (scalar)
+    // l-side of the first pass: its addresses depend only on the entry
+    bool act = slot < 7 && slot < nrem;
+    int ol = o + (act ? slot : 0);
+    int l = cam_idx[ol];
+    const double2 *ql = rec + (size_t)ol * REC;
+    double2 x0 = ql[0], x1 = ql[1], x2 = ql[2], cs = ql[sel];
+    // k-side: ONE line, wave-uniform scalar loads
+    const auto *qk = rec_c + (size_t)o * (2 * REC);
+    const double kx00 = qk[0], kx10 = qk[1], kx01 = qk[2], kx11 = qk[3], kx02 = qk[4], kx12 = qk[5];
+    const double kf0 = qk[6], kf1 = qk[7];
+    const double kw00 = qk[8], kw10 = qk[9], kw01 = qk[10], kw11 = qk[11], kw02 = qk[12], kw12 = qk[13];
+    const double ke0 = qk[14], ke1 = qk[15];
+    const auto *pb = PBc + 10 * (size_t)a;
     const double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
     const double v0 = pb[6], v1 = pb[7], v2 = pb[8];
     for (int base = 0; base < nrem; base += 7) {
-      const int it = base + slot;
-      if (slot < 7 && it < nrem) {
-        const int ol = o + it;
-        const int l = cam_idx[ol];
-        if (l >= l_lo && l < l_hi) {
-          const double2 x0 = JX[ol], x1 = JX[nobs + ol], x2 = JX[2 * nobs + ol];
-          const double2 cj = JC[(size_t)j * nobs + ol];
-          const double g0 = 2.0 * (x0.x * cj.x + x0.y * cj.y);  // F_al[:, j]
-          const double g1 = 2.0 * (x1.x * cj.x + x1.y * cj.y);
-          const double g2 = 2.0 * (x2.x * cj.x + x2.y * cj.y);
-          const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // E^-1 F_al[:, j]
-          const double h1 = i01 * g0 + i11 * g1 + i12 * g2;
-          const double h2 = i02 * g0 + i12 * g1 + i22 * g2;
-          const double t0 = 2.0 * (jxk[0].x * h0 + jxk[1].x * h1 + jxk[2].x * h2);
-          const double t1 = 2.0 * (jxk[0].y * h0 + jxk[1].y * h1 + jxk[2].y * h2);
-          const int col = 9 * (l - l_lo) + j;
-          const bool diag = (it == 0);
+      if (base > 0) {
+        const int it = base + slot;
+        act = slot < 7 && it < nrem;
+        ol = o + (act ? it : 0);
+        l = cam_idx[ol];
+        ql = rec + (size_t)ol * REC;
+        x0 = ql[0]; x1 = ql[1]; x2 = ql[2]; cs = ql[sel];
+      }
+      if (act && l >= l_lo && l < l_hi) {
+        // J_C column j of the l-side observation
+        double2 cj = cs;
+        if (j >= 3 && j < 6) cj = make_double2(-cs.x, -cs.y);
+        if (j == 1) cj = make_double2(cu, 0.0);
+        if (j == 2) cj = make_double2(0.0, cu);
+        const double g0 = 2.0 * (x0.x * cj.x + x0.y * cj.y);  // F_al[:, j]
+        const double g1 = 2.0 * (x1.x * cj.x + x1.y * cj.y);
+        const double g2 = 2.0 * (x2.x * cj.x + x2.y * cj.y);
+        const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // E^-1 F_al[:, j]
+        const double h1 = i01 * g0 + i11 * g1 + i12 * g2;
+        const double h2 = i02 * g0 + i12 * g1 + i22 * g2;
+        const double t0 = 2.0 * (kx00 * h0 + kx01 * h1 + kx02 * h2);
+        const double t1 = 2.0 * (kx10 * h0 + kx11 * h1 + kx12 * h2);
+        // -(Jc_k[:, i] . t) for i = f, u, v, t(3), omega(3)
+        double val[9];
+        val[0] = -(kf0 * t0 + kf1 * t1);
+        val[1] = -(cu * t0);
+        val[2] = -(cu * t1);
+        val[3] = kx00 * t0 + kx10 * t1;
+        val[4] = kx01 * t0 + kx11 * t1;
+        val[5] = kx02 * t0 + kx12 * t1;
+        val[6] = -(kw00 * t0 + kw10 * t1);
+        val[7] = -(kw01 * t0 + kw11 * t1);
+        val[8] = -(kw02 * t0 + kw12 * t1);
+        if (base + slot == 0) {  // diagonal item (l == k): + G^_k and the right-hand side
+          const double d0 = 2.0 * cj.x, d1 = 2.0 * cj.y;
+          double gg[9];
+          gg[0] = kf0 * d0 + kf1 * d1;
+          gg[1] = cu * d0;
+          gg[2] = cu * d1;
+          gg[3] = -(kx00 * d0 + kx10 * d1);
+          gg[4] = -(kx01 * d0 + kx11 * d1);
+          gg[5] = -(kx02 * d0 + kx12 * d1);
+          gg[6] = kw00 * d0 + kw10 * d1;
+          gg[7] = kw01 * d0 + kw11 * d1;
+          gg[8] = kw02 * d0 + kw12 * d1;
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            double val = -(jck[i].x * t0 + jck[i].y * t1);
-            if (diag) {
-              double gg = 2.0 * (jck[i].x * cj.x + jck[i].y * cj.y);
-              if (i == j) gg *= damp;
-              val += gg;
-            }
-            atomicAdd(&strip[i * W + col], val);
-          }
-          if (diag) {
-            const double w0 = jxk[0].x * v0 + jxk[1].x * v1 + jxk[2].x * v2 - ek.x;
-            const double w1 = jxk[0].y * v0 + jxk[1].y * v1 + jxk[2].y * v2 - ek.y;
-            atomicAdd(&sb[j], 2.0 * (cj.x * w0 + cj.y * w1));
-          }
+          for (int i = 0; i < 9; ++i) val[i] += (i == j) ? gg[i] * damp : gg[i];
+          const double w0 = kx00 * v0 + kx01 * v1 + kx02 * v2 - ke0;
+          const double w1 = kx10 * v0 + kx11 * v1 + kx12 * v2 - ke1;
+          atomicAdd(&sb[j], 2.0 * (cj.x * w0 + cj.y * w1));
         }
+        double *dst = strip + 9 * (l - l_lo) + j;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(dst + i * W, val[i]);
       }
     }
+    idx = idx_next;
   }
   __syncthreads();
   const size_t ld = 9 * (size_t)m;
@@ -391,8 +475,8 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 // One thread per point: dX_a = -E^-1 (sum_k F_ak dxi_k + dP_a), X' = X + dX, then the
 // point's residuals at the trial cameras.  partials[block] = block cost (fixed tree).
 __global__ __launch_bounds__(256) void k_backsub_cost(
-    long long npts, long long nobs, int m, const long long *__restrict__ pt_ptr, const int *__restrict__ cam_idx,
-    const double2 *__restrict__ xy, const double2 *__restrict__ JX, const double2 *__restrict__ JC,
+    long long npts, int m, const long long *__restrict__ pt_ptr, const int *__restrict__ cam_idx,
+    const double2 *__restrict__ xy, const double2 *__restrict__ rec,
     const double *__restrict__ PB, const double *__restrict__ dxi, const double *__restrict__ X,
     const double *__restrict__ cam15_trial, double f0, double *__restrict__ Xt, double *__restrict__ dX,
     double *__restrict__ partials) {
@@ -407,16 +491,16 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
   if (a < npts) {
     const long long o0 = pt_ptr[a], o1 = pt_ptr[a + 1];
     double acc0 = 0, acc1 = 0, acc2 = 0;
+    const double cu = 1.0 / f0;
     for (long long o = o0; o < o1; ++o) {
       const double *dk = s_dxi + 9 * cam_idx[o];
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        const double2 cj = JC[(size_t)p * nobs + o];
-        s0 += cj.x * dk[p];
-        s1 += cj.y * dk[p];
-      }
-      const double2 x0 = JX[o], x1 = JX[nobs + o], x2 = JX[2 * nobs + o];
+      const double2 *q = rec + o * REC;
+      const double2 x0 = q[0], x1 = q[1], x2 = q[2], jf = q[3], w0 = q[4], w1 = q[5], w2 = q[6];
+      // s = J_C dxi_k with the implied columns: (u,v) -> 1/f0, t -> -J_X
+      const double s0 = jf.x * dk[0] + cu * dk[1] - (x0.x * dk[3] + x1.x * dk[4] + x2.x * dk[5]) +
+                        (w0.x * dk[6] + w1.x * dk[7] + w2.x * dk[8]);
+      const double s1 = jf.y * dk[0] + cu * dk[2] - (x0.y * dk[3] + x1.y * dk[4] + x2.y * dk[5]) +
+                        (w0.y * dk[6] + w1.y * dk[7] + w2.y * dk[8]);
       acc0 += 2.0 * (x0.x * s0 + x0.y * s1);
       acc1 += 2.0 * (x1.x * s0 + x1.y * s1);
       acc2 += 2.0 * (x2.x * s0 + x2.y * s1);
@@ -466,17 +550,6 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict_
   if (threadIdx.x == 0) *out = t;
 }
 
-// debug: planes -> canonical [n_obs][2][P]
-__global__ void k_planes_to_rows(long long nobs, int P, const double2 *__restrict__ planes, double *__restrict__ out) {
-  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= nobs) return;
-  for (int p = 0; p < P; ++p) {
-    const double2 v = planes[(size_t)p * nobs + o];
-    out[(size_t)o * 2 * P + p] = v.x;
-    out[(size_t)o * 2 * P + P + p] = v.y;
-  }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------ host side
@@ -492,13 +565,13 @@ struct mvba_handle {
   double2 *d_xy = nullptr;
   int4 *d_csc = nullptr;
   long long *d_chunk_ptr = nullptr;
-  int nchunks = 1, lseg = 0, nseg = 1;
+  int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 1024;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
   bool have_params = false, linearized = false, have_trial = false;
   // linearisation
-  double2 *d_e = nullptr, *d_JX = nullptr, *d_JC = nullptr;
+  double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
   double *d_Ab = nullptr, *d_Ared = nullptr, *d_bred = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
@@ -668,6 +741,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   // Schur launch geometry: ~3000 blocks, >= 256 camera-list entries per block
   const long long avg_len = std::max<long long>(1, nobs / m);
   h->nchunks = (int)std::max<long long>(1, std::min<long long>((3072 + m - 1) / m, avg_len / 256));
+  // tuning overrides (experiments only)
+  if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(1024, atoi(ev) / 64 * 64));
+  if (const char *ev = getenv("MVBA_SCHUR_CHUNKS")) h->nchunks = std::max(1, atoi(ev));
   const size_t lds_cap = 150 * 1024;
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
   h->nseg = (m + h->lseg - 1) / h->lseg;
@@ -694,9 +770,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_csc, nobs));
   TRY(dmalloc(&h->d_chunk_ptr, chunk_ptr.size()));
   for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
-  TRY(dmalloc(&h->d_e, nobs));
-  TRY(dmalloc(&h->d_JX, 3 * nobs));
-  TRY(dmalloc(&h->d_JC, 9 * nobs));
+  TRY(dmalloc(&h->d_rec, (size_t)REC * nobs));
   TRY(dmalloc(&h->d_PL, 9 * N));
   TRY(dmalloc(&h->d_PB, 10 * N));
   const size_t n9 = 9 * (size_t)m;
@@ -724,7 +798,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->D * sizeof(double))));
 #undef TRY
@@ -739,7 +814,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_e, h->d_JX, h->d_JC, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared,
                   h->d_bred, h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -798,17 +873,17 @@ int mvba_linearize(mvba_handle *h) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
   MVBA_HIP(hipSetDevice(h->device));
-  const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
   if (h->nobs) {
     Timed t(h, MVBA_K_RESID_JAC);
+    const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double);
     const int grid = (int)std::min<long long>(2048, (h->nobs + 255) / 256);
     hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(256), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
-                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_e, h->d_JX, h->d_JC);
+                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_rec);
   }
   if (h->N) {
     Timed t(h, MVBA_K_POINT_BLOCKS);
-    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nobs,
-                       h->d_pt_ptr, h->d_e, h->d_JX, h->d_PL);
+    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N,
+                       h->d_pt_ptr, h->d_rec, h->d_PL);
   }
   MVBA_HIP(hipGetLastError());
   h->linearized = true; h->have_trial = false;
@@ -832,8 +907,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
-    hipLaunchKernelGGL(k_schur_strip, dim3(m, h->nchunks, h->nseg), dim3(1024), lds, h->stream, m, h->nchunks, h->lseg,
-                       h->nobs, h->d_chunk_ptr, h->d_csc, h->d_cam, h->d_e, h->d_JX, h->d_JC, h->d_PB, c, d_A, d_b);
+    hipLaunchKernelGGL(k_schur_strip, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg,
+                       h->d_chunk_ptr, h->d_csc, h->d_cam, h->d_rec, h->d_PB, c, h->f0, d_A, d_b);
   }
   MVBA_HIP(hipGetLastError());
   if (h->comm) {
@@ -867,8 +942,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int nblk = (int)((h->N + 255) / 256);
     if (nblk) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
-      hipLaunchKernelGGL(k_backsub_cost, dim3(nblk), dim3(256), lds, h->stream, h->N, h->nobs, m, h->d_pt_ptr, h->d_cam,
-                         h->d_xy, h->d_JX, h->d_JC, h->d_PB, h->d_dxi, h->d_X[h->cur], h->d_cam15[trial], h->f0,
+      hipLaunchKernelGGL(k_backsub_cost, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam,
+                         h->d_xy, h->d_rec, h->d_PB, h->d_dxi, h->d_X[h->cur], h->d_cam15[trial], h->f0,
                          h->d_X[trial], h->d_dX, h->d_partials);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost);
@@ -967,16 +1042,26 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
   MVBA_HIP(hipStreamSynchronize(h->stream));
   auto d2h = [&](const void *src, size_t bytes) { return hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost); };
   if (which == MVBA_BUF_RESIDUAL || which == MVBA_BUF_JX || which == MVBA_BUF_JC) {
-    const int P = which == MVBA_BUF_RESIDUAL ? 1 : (which == MVBA_BUF_JX ? 3 : 9);
-    const double2 *src = which == MVBA_BUF_RESIDUAL ? h->d_e : (which == MVBA_BUF_JX ? h->d_JX : h->d_JC);
-    double *tmp = nullptr;
-    MVBA_HIP(hipMalloc((void **)&tmp, sizeof(double) * std::max<long long>(cnt, 1)));
-    if (h->nobs)
-      hipLaunchKernelGGL(k_planes_to_rows, dim3((unsigned)((h->nobs + 255) / 256)), dim3(256), 0, h->stream, h->nobs, P, src, tmp);
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = d2h(tmp, sizeof(double) * cnt);
-    hipFree(tmp);
-    MVBA_HIP(e);
+    std::vector<double> r((size_t)2 * REC * h->nobs);  // expand the records on the host
+    MVBA_HIP(hipMemcpy(r.data(), h->d_rec, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
+    const double cu = 1.0 / h->f0;
+    for (long long o = 0; o < h->nobs; ++o) {
+      const double *q = r.data() + (size_t)o * 2 * REC;  // slot s -> (q[2s], q[2s+1]) = (row0, row1)
+      if (which == MVBA_BUF_RESIDUAL) {
+        out[2 * o] = q[14]; out[2 * o + 1] = q[15];
+      } else if (which == MVBA_BUF_JX) {
+        for (int rr = 0; rr < 2; ++rr) for (int i = 0; i < 3; ++i) out[6 * o + 3 * rr + i] = q[2 * i + rr];
+      } else {
+        double *jc = out + 18 * o;
+        for (int rr = 0; rr < 2; ++rr) {
+          jc[9 * rr + 0] = q[6 + rr];
+          jc[9 * rr + 1] = rr == 0 ? cu : 0.0;
+          jc[9 * rr + 2] = rr == 1 ? cu : 0.0;
+          for (int i = 0; i < 3; ++i) jc[9 * rr + 3 + i] = -q[2 * i + rr];
+          for (int i = 0; i < 3; ++i) jc[9 * rr + 6 + i] = q[8 + 2 * i + rr];
+        }
+      }
+    }
   } else if (which == MVBA_BUF_E || which == MVBA_BUF_DP) {
     std::vector<double> pl(9 * (size_t)h->N);
     MVBA_HIP(hipMemcpy(pl.data(), h->d_PL, sizeof(double) * pl.size(), hipMemcpyDeviceToHost));
