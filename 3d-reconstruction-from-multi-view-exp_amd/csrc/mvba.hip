@@ -193,7 +193,10 @@ __device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
 #pragma clang diagnostic pop
 }
 
-__global__ __launch_bounds__(1024, 8) void k_schur_strip(
+// LDS strip layout: strip[(9 (l - l_lo) + j) * 9 + i]  (i fastest) so that the nine
+// accumulations of a lane are ONE address + immediate offsets; sb (rhs) follows.
+template <bool BIG>  // BIG: record byte offsets need 64 bits (n_obs * 128 >= 4 GiB)
+__global__ __launch_bounds__(768, 6) void k_schur_strip(
     int m, int nchunks, int lseg, const long long *__restrict__ chunk_ptr, const int4 *__restrict__ csc,
     const int *__restrict__ cam_idx, const double2 *__restrict__ rec, const double *__restrict__ PB, double c,
     double f0, double *__restrict__ Afull, double *__restrict__ bfull) {
@@ -214,9 +217,12 @@ __global__ __launch_bounds__(1024, 8) void k_schur_strip(
   const int nw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slot = lane / 9, j = lane - 9 * slot;
-  // which record slot holds J_C column j, and how to turn it into the column (see file header)
-  const int sel = (j == 0) ? 3 : (j >= 6 ? j - 2 : (j >= 3 ? j - 3 : 0));
+  // J_C column j of an observation = alpha * record_slot[sel] + beta  (see file header);
+  // the factor 4 = 2 (F = 2 Jx^T Jc) * 2 (t = 2 Jx_k h) is folded in here.
+  const unsigned sel16 = 16u * ((j == 0) ? 3 : (j >= 6 ? j - 2 : (j >= 3 ? j - 3 : 0)));
   const double cu = 1.0 / f0;
+  const double alpha = (j == 1 || j == 2) ? 0.0 : ((j >= 3 && j < 6) ? -4.0 : 4.0);
+  const double beta_x = (j == 1) ? 4.0 * cu : 0.0, beta_y = (j == 2) ? 4.0 * cu : 0.0;
   const long long beg = chunk_ptr[(size_t)k * (nchunks + 1) + chunk];
   const long long end = chunk_ptr[(size_t)k * (nchunks + 1) + chunk + 1];
   const double damp = 1.0 + c;
@@ -224,55 +230,58 @@ __global__ __launch_bounds__(1024, 8) void k_schur_strip(
   const auto *csc_c = as_const(reinterpret_cast<const int *>(csc));
   const auto *rec_c = as_const(reinterpret_cast<const double *>(rec));
   const auto *PBc = as_const(PB);
+  const char *recb = reinterpret_cast<const char *>(rec);
   auto load_rec = [&](long long i) { return make_int4(csc_c[4 * i], csc_c[4 * i + 1], csc_c[4 * i + 2], 0); };
+  auto line = [&](int ol) -> const char * {
+    if (BIG) return recb + ((size_t)ol << 7);
+    return recb + ((unsigned)ol << 7);  // scalar base + 32-bit lane offset
+  };
 
+  // ---- software-pipelined walk over (entry, pass) pairs --------------------------------
+  // Scalar loads (SMEM) and LDS atomics share lgkmcnt and SMEM returns out of order, so a
+  // wait for the k-side operands is always lgkmcnt(0) and would also wait for every LDS
+  // atomic still queued behind 31 other waves.  Order per iteration therefore:
+  //   compute(pass n) -> issue loads for pass n+1 (vector l-side, scalar k-side if the
+  //   entry changes) -> s_waitcnt lgkmcnt(0) -> issue the 9 atomics of pass n.
+  // The atomics then drain under the compute of pass n+1.
   long long idx = beg + wave;
-  int4 cur = make_int4(0, 0, 0, 0);
-  if (idx < end) cur = load_rec(idx);
-  while (idx < end) {
-    const int o = cur.x, a = cur.y, nrem = cur.z;
-    const long long idx_next = idx + nw;
-    if (idx_next < end) cur = load_rec(idx_next);  // prefetch the next camera-list entry (scalar)
-    // l-side of the first pass: its addresses depend only on the entry
-    bool act = slot < 7 && slot < nrem;
-    int ol = o + (act ? slot : 0);
+  if (idx < end) {
+    int4 cur = load_rec(idx);
+    int4 nxt = (idx + nw < end) ? load_rec(idx + nw) : cur;
+    int base = 0;
+    // k-side: ONE record line + the point block, wave-uniform scalar loads
+    const double MVBA_CONST_AS *qk = rec_c + (size_t)cur.x * (2 * REC);
+    const double MVBA_CONST_AS *pb = PBc + 10 * (size_t)cur.y;
+    double kx00 = qk[0], kx10 = qk[1], kx01 = qk[2], kx11 = qk[3], kx02 = qk[4], kx12 = qk[5];
+    double kf0 = qk[6], kf1 = qk[7];
+    double kw00 = qk[8], kw10 = qk[9], kw01 = qk[10], kw11 = qk[11], kw02 = qk[12], kw12 = qk[13];
+    double ke0 = qk[14], ke1 = qk[15];
+    double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
+    double v0 = pb[6], v1 = pb[7], v2 = pb[8];
+    // l-side of the first pass
+    bool act = slot < cur.z;
+    int ol = cur.x + (act ? slot : 0);
     int l = cam_idx[ol];
-    const double2 *ql = rec + (size_t)ol * REC;
-    double2 x0 = ql[0], x1 = ql[1], x2 = ql[2], cs = ql[sel];
-    // k-side: ONE line, wave-uniform scalar loads
-    const auto *qk = rec_c + (size_t)o * (2 * REC);
-    const double kx00 = qk[0], kx10 = qk[1], kx01 = qk[2], kx11 = qk[3], kx02 = qk[4], kx12 = qk[5];
-    const double kf0 = qk[6], kf1 = qk[7];
-    const double kw00 = qk[8], kw10 = qk[9], kw01 = qk[10], kw11 = qk[11], kw02 = qk[12], kw12 = qk[13];
-    const double ke0 = qk[14], ke1 = qk[15];
-    const auto *pb = PBc + 10 * (size_t)a;
-    const double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
-    const double v0 = pb[6], v1 = pb[7], v2 = pb[8];
-    for (int base = 0; base < nrem; base += 7) {
-      if (base > 0) {
-        const int it = base + slot;
-        act = slot < 7 && it < nrem;
-        ol = o + (act ? it : 0);
-        l = cam_idx[ol];
-        ql = rec + (size_t)ol * REC;
-        x0 = ql[0]; x1 = ql[1]; x2 = ql[2]; cs = ql[sel];
-      }
-      if (act && l >= l_lo && l < l_hi) {
-        // J_C column j of the l-side observation
-        double2 cj = cs;
-        if (j >= 3 && j < 6) cj = make_double2(-cs.x, -cs.y);
-        if (j == 1) cj = make_double2(cu, 0.0);
-        if (j == 2) cj = make_double2(0.0, cu);
-        const double g0 = 2.0 * (x0.x * cj.x + x0.y * cj.y);  // F_al[:, j]
-        const double g1 = 2.0 * (x1.x * cj.x + x1.y * cj.y);
-        const double g2 = 2.0 * (x2.x * cj.x + x2.y * cj.y);
-        const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // E^-1 F_al[:, j]
+    const char *ql = line(ol);
+    double2 x0 = *reinterpret_cast<const double2 *>(ql), x1 = *reinterpret_cast<const double2 *>(ql + 16),
+            x2 = *reinterpret_cast<const double2 *>(ql + 32), cs = *reinterpret_cast<const double2 *>(ql + sel16);
+    while (true) {
+      // ---------------- compute pass n
+      const bool valid = act && slot < 7 && l >= l_lo && l < l_hi;
+      double *dst = strip + (9 * (l - l_lo) + j) * 9;
+      const bool diag = valid && (base + slot == 0);
+      double val[9], bval = 0.0;
+      {
+        const double cjx = alpha * cs.x + beta_x, cjy = alpha * cs.y + beta_y;  // 4 * Jc_l[:, j]
+        const double g0 = x0.x * cjx + x0.y * cjy;  // 2 * F_al[:, j]
+        const double g1 = x1.x * cjx + x1.y * cjy;
+        const double g2 = x2.x * cjx + x2.y * cjy;
+        const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // 2 * E^-1 F_al[:, j]
         const double h1 = i01 * g0 + i11 * g1 + i12 * g2;
         const double h2 = i02 * g0 + i12 * g1 + i22 * g2;
-        const double t0 = 2.0 * (kx00 * h0 + kx01 * h1 + kx02 * h2);
-        const double t1 = 2.0 * (kx10 * h0 + kx11 * h1 + kx12 * h2);
-        // -(Jc_k[:, i] . t) for i = f, u, v, t(3), omega(3)
-        double val[9];
+        const double t0 = kx00 * h0 + kx01 * h1 + kx02 * h2;  // 2 Jx_k E^-1 F_al[:, j]
+        const double t1 = kx10 * h0 + kx11 * h1 + kx12 * h2;
+        // -(Jc_k[:, i] . t) for i = f, u, v, t(3), omega(3)   (t columns of Jc are -Jx)
         val[0] = -(kf0 * t0 + kf1 * t1);
         val[1] = -(cu * t0);
         val[2] = -(cu * t1);
@@ -282,8 +291,8 @@ __global__ __launch_bounds__(1024, 8) void k_schur_strip(
         val[6] = -(kw00 * t0 + kw10 * t1);
         val[7] = -(kw01 * t0 + kw11 * t1);
         val[8] = -(kw02 * t0 + kw12 * t1);
-        if (base + slot == 0) {  // diagonal item (l == k): + G^_k and the right-hand side
-          const double d0 = 2.0 * cj.x, d1 = 2.0 * cj.y;
+        if (diag) {  // diagonal item (l == k): + G^_k and the right-hand side
+          const double d0 = 0.5 * cjx, d1 = 0.5 * cjy;  // 2 * Jc_k[:, j]
           double gg[9];
           gg[0] = kf0 * d0 + kf1 * d1;
           gg[1] = cu * d0;
@@ -298,148 +307,227 @@ __global__ __launch_bounds__(1024, 8) void k_schur_strip(
           for (int i = 0; i < 9; ++i) val[i] += (i == j) ? gg[i] * damp : gg[i];
           const double w0 = kx00 * v0 + kx01 * v1 + kx02 * v2 - ke0;
           const double w1 = kx10 * v0 + kx11 * v1 + kx12 * v2 - ke1;
-          atomicAdd(&sb[j], 2.0 * (cj.x * w0 + cj.y * w1));
+          bval = d0 * w0 + d1 * w1;
         }
-        double *dst = strip + 9 * (l - l_lo) + j;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(dst + i * W, val[i]);
       }
+      // ---------------- advance to pass n+1 and issue its loads
+      bool done = false;
+      if (base + 7 < cur.z) {
+        base += 7;
+      } else {
+        idx += nw;
+        if (idx >= end) {
+          done = true;
+        } else {
+          cur = nxt;
+          base = 0;
+          if (idx + nw < end) nxt = load_rec(idx + nw);
+          qk = rec_c + (size_t)cur.x * (2 * REC);
+          pb = PBc + 10 * (size_t)cur.y;
+          kx00 = qk[0]; kx10 = qk[1]; kx01 = qk[2]; kx11 = qk[3]; kx02 = qk[4]; kx12 = qk[5];
+          kf0 = qk[6]; kf1 = qk[7];
+          kw00 = qk[8]; kw10 = qk[9]; kw01 = qk[10]; kw11 = qk[11]; kw02 = qk[12]; kw12 = qk[13];
+          ke0 = qk[14]; ke1 = qk[15];
+          i00 = pb[0]; i01 = pb[1]; i02 = pb[2]; i11 = pb[3]; i12 = pb[4]; i22 = pb[5];
+          v0 = pb[6]; v1 = pb[7]; v2 = pb[8];
+        }
+      }
+      if (!done) {
+        const int it = base + slot;
+        act = it < cur.z;
+        ol = cur.x + (act ? it : 0);
+        l = cam_idx[ol];
+        ql = line(ol);
+        x0 = *reinterpret_cast<const double2 *>(ql); x1 = *reinterpret_cast<const double2 *>(ql + 16);
+        x2 = *reinterpret_cast<const double2 *>(ql + 32); cs = *reinterpret_cast<const double2 *>(ql + sel16);
+      }
+      // the scalar loads above must have landed BEFORE the atomics enter the LDS queue
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- the 9 accumulations of pass n (asynchronous from here on)
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(dst + i, val[i]);
+        if (diag) atomicAdd(&sb[j], bval);
+      }
+      if (done) break;
     }
-    idx = idx_next;
   }
   __syncthreads();
   const size_t ld = 9 * (size_t)m;
-  for (int i = threadIdx.x; i < 9 * W; i += blockDim.x) {
-    const int row = i / W, col = i - row * W;
-    const double val = strip[i];
+  for (int q = threadIdx.x; q < 9 * W; q += blockDim.x) {
+    const int row = q / W, col = q - row * W;  // coalesced over the columns of A
+    const double val = strip[col * 9 + row];
     if (val != 0.0) atomicAdd(&Afull[(9 * (size_t)k + row) * ld + 9 * (size_t)l_lo + col], val);
   }
   if (seg == 0 && threadIdx.x < 9) atomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ K4: gauge strip + Cholesky
-__global__ void k_compact(int D, int m, int gauge_axis, const double *__restrict__ Afull,
-                          const double *__restrict__ bfull, double *__restrict__ Ared,
-                          double *__restrict__ bred) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-  if (j >= D) return;
-  const int gi = keep_index(i, gauge_axis), gj = keep_index(j, gauge_axis);
-  const size_t ld = 9 * (size_t)m;
-  // only the upper block triangle of Afull is populated: read (min,max)
-  const int r = min(gi, gj), cidx = max(gi, gj);
-  Ared[(size_t)i * D + j] = Afull[(size_t)r * ld + cidx];
-  if (j == 0) bred[i] = bfull[gi];
-}
-
+// The reduced system is SPD (Gauss-Newton Schur complement with Marquardt damping), so
+// the reference's np.linalg.solve (LU, ref :146) is replaced by a blocked Cholesky
+// (parity-safe).  Storage: M = (D+1) x ld row-major, lower triangle of A in
+// rows 0..D-1 and the right-hand side b as ROW D, so that factorising carries the forward
+// substitution along (row D ends up holding y = L^-1 b).  Per 32-column panel:
+//   k_chol_panel  one wave per 64 rows: every wave re-factors the 32x32 diagonal tile in
+//                 LDS (wave-synchronous, no barriers), then solves X L^T = P for its rows
+//   k_chol_trail  trailing update C -= P P^T on v_mfma_f64_16x16x4_f64, 32x32 per wave
+// then k_chol_backsolve does L^T x = y in one workgroup with LDS-staged tiles.
 constexpr int NB = 32;
 
-// factor the nb x nb diagonal block at (j0,j0), lower, in place
-__global__ __launch_bounds__(1024) void k_chol_diag(double *A, int D, int j0, int nb, int *flag) {
-  __shared__ double T[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const bool in = r < nb && c < nb;
-  T[r][c] = in ? A[(size_t)(j0 + r) * D + j0 + c] : (r == c ? 1.0 : 0.0);
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    if (r == k && c == k) {
-      const double d = T[k][k];
-      if (!(d > 0.0)) atomicOr(flag, 2);  // not SPD -> reported as singular
-      T[k][k] = sqrt(d);
+__global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
+                          const double *__restrict__ bfull, double *__restrict__ M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // i in [0, D], j in [0, D)
+  if (j >= D) return;
+  const int gj = keep_index(j, gauge_axis);
+  if (i == D) {
+    M[(size_t)D * ld + j] = bfull[gj];
+    return;
+  }
+  if (j > i) return;
+  const int gi = keep_index(i, gauge_axis);
+  const size_t l9 = 9 * (size_t)m;
+  // only the upper block triangle of Afull is populated: read (min,max)
+  M[(size_t)i * ld + j] = Afull[(size_t)min(gi, gj) * l9 + max(gi, gj)];
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// One wave per 64 rows.  Lane r (mod 32) keeps row r of the diagonal tile in registers;
+// entries of L are broadcast with v_readlane (SGPR operands): no LDS, no barriers, every
+// index static.  Every wave re-factors the tile (cheap) so the panel needs one launch.
+__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int ld, int D, int j0, int nb,
+                                                   int *__restrict__ flag) {
+  const int lane = threadIdx.x;
+  const int r = lane & 31;
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double v = (r == c) ? 1.0 : 0.0;  // identity padding beyond nb
+    if (r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c];
+    a[c] = v;
+  }
+  bool bad = false;
+  double rinv[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const double piv = readlane_d(a[k], k);
+    bad |= !(piv > 0.0);
+    const double lkk = sqrt(piv);
+    rinv[k] = 1.0 / lkk;
+    a[k] = (r == k) ? lkk : a[k] * rinv[k];
+#pragma unroll
+    for (int c = k + 1; c < NB; ++c) {
+      const double lck = readlane_d(a[k], c);
+      if (r >= c) a[c] -= a[k] * lck;
     }
-    __syncthreads();
-    if (c == k && r > k) T[r][k] /= T[k][k];
-    __syncthreads();
-    if (r > k && c > k && c <= r) T[r][c] -= T[r][k] * T[c][k];
-    __syncthreads();
   }
-  if (in && c <= r) A[(size_t)(j0 + r) * D + j0 + c] = T[r][c];
-}
-
-// rows below the diagonal block: X = P L^-T
-__global__ __launch_bounds__(1024) void k_chol_panel(double *A, int D, int j0, int nb) {
-  __shared__ double L[NB][NB + 1], P[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const int row = j0 + nb + blockIdx.x * NB + r;
-  L[r][c] = (r < nb && c < nb) ? A[(size_t)(j0 + r) * D + j0 + c] : (r == c ? 1.0 : 0.0);
-  P[r][c] = (row < D && c < nb) ? A[(size_t)row * D + j0 + c] : 0.0;
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    if (c == k) P[r][k] /= L[k][k];
-    __syncthreads();
-    if (c > k) P[r][c] -= P[r][k] * L[c][k];
-    __syncthreads();
+  if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+  if (blockIdx.x == 0 && lane < NB && r < nb) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c <= r && c < nb) M[(size_t)(j0 + r) * ld + j0 + c] = a[c];
   }
-  if (row < D && c < nb) A[(size_t)row * D + j0 + c] = P[r][c];
-}
-
-// trailing update, lower tiles only: A[r][c] -= sum_k P[r][k] P[c][k]
-__global__ __launch_bounds__(1024) void k_chol_trail(double *A, int D, int j0, int nb) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  __shared__ double Pi[NB][NB + 1], Pj[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const int t0 = j0 + nb;
-  const int gr = t0 + ti * NB + r, gc0 = t0 + tj * NB + r;
-  Pi[r][c] = (gr < D && c < nb) ? A[(size_t)gr * D + j0 + c] : 0.0;
-  Pj[r][c] = (gc0 < D && c < nb) ? A[(size_t)gc0 * D + j0 + c] : 0.0;
-  __syncthreads();
-  const int gc = t0 + tj * NB + c;
-  if (gr < D && gc < D && gc <= gr) {
-    double s = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) s += Pi[r][k] * Pj[c][k];
-    A[(size_t)gr * D + gc] -= s;
+  // rows below the tile (row D = rhs included): X L^T = P, one row per lane
+  const int row = j0 + nb + blockIdx.x * 64 + lane;
+  const bool live = row <= D;
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = (live && c < nb) ? M[(size_t)row * ld + j0 + c] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    x[k] = x[k] * rinv[k];
+#pragma unroll
+    for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * readlane_d(a[k], c);
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb) M[(size_t)row * ld + j0 + c] = x[c];
   }
 }
 
-// L y = b then L^T x = y, single block; then scatter to the full 9m vector.
-__global__ __launch_bounds__(1024) void k_chol_solve(const double *__restrict__ L, int D, const double *__restrict__ b,
-                                                     int m, int gauge_axis, double *__restrict__ dxi_full) {
-  extern __shared__ double y[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < D; i += blockDim.x) y[i] = b[i];
-  __syncthreads();
-  for (int jb = 0; jb < D; jb += NB) {  // forward
-    const int nb = min(NB, D - jb);
-    if (wave == 0) {
-      double yr = (lane < nb) ? y[jb + lane] : 0.0;
-      for (int k = 0; k < nb; ++k) {
-        const double yk = __shfl(yr, k, 64) / L[(size_t)(jb + k) * D + jb + k];
-        if (lane == k) yr = yk;
-        if (lane > k && lane < nb) yr -= L[(size_t)(jb + lane) * D + jb + k] * yk;
+typedef double mvba_d4 __attribute__((ext_vector_type(4)));
+
+// Trailing update with f64 MFMA.  Block = 4 waves = 64x64 output tile, wave = 32x32.
+// A operand: lane l holds P[row0 + (l & 15)][k = 4 kk + (l >> 4)]; B operand the same
+// from the column tile (B[k][n] = P[col0 + n][k]); C/D: col = l & 15, row = (l >> 4) + 4 reg.
+__global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int ld, int D, int j0) {
+  const int t0 = j0 + NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = t0 + blockIdx.y * 64 + (wave >> 1) * 32;
+  const int c0 = t0 + blockIdx.x * 64 + (wave & 1) * 32;
+  if (c0 > r0 + 31 || r0 > D || c0 >= D) return;  // strictly upper tile or out of range
+  mvba_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    double av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rr = r0 + 16 * i + li, cc = c0 + 16 * i + li;
+      av[i] = (rr <= D) ? M[(size_t)rr * ld + j0 + 4 * kk + lk] : 0.0;
+      bv[i] = (cc < D) ? M[(size_t)cc * ld + j0 + 4 * kk + lk] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = r0 + 16 * i + lk + 4 * q, cc = c0 + 16 * j + li;
+        if (rr <= D && cc < D && (cc <= rr)) M[(size_t)rr * ld + cc] -= acc[i][j][q];
       }
-      if (lane < nb) y[jb + lane] = yr;
-    }
-    __syncthreads();
-    for (int r = jb + nb + tid; r < D; r += blockDim.x) {
-      double s = 0.0;
-      for (int cc = 0; cc < nb; ++cc) s += L[(size_t)r * D + jb + cc] * y[jb + cc];
-      y[r] -= s;
-    }
-    __syncthreads();
-  }
+}
+
+// L^T x = y (y = row D), single workgroup; scatter x into the full 9m vector (zeros at the gauge slots).
+__global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restrict__ M, int ld, int D, int m,
+                                                         int gauge_axis, double *__restrict__ dxi_full) {
+  extern __shared__ double y[];  // D doubles
+  __shared__ double T[NB][NB + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D; i += blockDim.x) y[i] = M[(size_t)D * ld + i];
+  for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
+  __syncthreads();
   const int nblk = (D + NB - 1) / NB;
-  for (int bi = nblk - 1; bi >= 0; --bi) {  // backward with L^T
+  for (int bi = nblk - 1; bi >= 0; --bi) {
     const int jb = bi * NB, nb = min(NB, D - jb);
+    {
+      const int r = tid / NB, c = tid % NB;  // 1024 threads = one tile
+      T[r][c] = (r < nb && c <= r) ? M[(size_t)(jb + r) * ld + jb + c] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
     if (wave == 0) {
       double xr = (lane < nb) ? y[jb + lane] : 0.0;
       for (int k = nb - 1; k >= 0; --k) {
-        const double xk = __shfl(xr, k, 64) / L[(size_t)(jb + k) * D + jb + k];
+        const double xk = __shfl(xr, k, 64) / T[k][k];
         if (lane == k) xr = xk;
-        if (lane < k) xr -= L[(size_t)(jb + k) * D + jb + lane] * xk;
+        if (lane < k) xr -= T[k][lane] * xk;
       }
       if (lane < nb) y[jb + lane] = xr;
     }
     __syncthreads();
     for (int cc = tid; cc < jb; cc += blockDim.x) {
-      double s = 0.0;
-      for (int r = 0; r < nb; ++r) s += L[(size_t)(jb + r) * D + cc] * y[jb + r];
-      y[cc] -= s;
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < nb; ++r) sacc += M[(size_t)(jb + r) * ld + cc] * y[jb + r];
+      y[cc] -= sacc;
     }
     __syncthreads();
   }
-  for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
-  __syncthreads();
   for (int i = tid; i < D; i += blockDim.x) dxi_full[keep_index(i, gauge_axis)] = y[i];
 }
 
@@ -557,7 +645,7 @@ struct mvba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   long long N = 0, nobs = 0;
-  int m = 0, gauge_axis = 0, D = 0;
+  int m = 0, gauge_axis = 0, D = 0, ld = 0;
   double f0 = 1.0;
   // topology
   long long *d_pt_ptr = nullptr;
@@ -565,7 +653,7 @@ struct mvba_handle {
   double2 *d_xy = nullptr;
   int4 *d_csc = nullptr;
   long long *d_chunk_ptr = nullptr;
-  int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 1024;
+  int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
@@ -574,7 +662,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_bred = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -736,13 +824,13 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     hipError_t e = hipGetDevice(&h->device);
     if (e != hipSuccess) { delete h; return fail(MVBA_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e)); }
   }
-  h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7;
+  h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7; h->ld = (h->D + 3) & ~3;
 
   // Schur launch geometry: ~3000 blocks, >= 256 camera-list entries per block
   const long long avg_len = std::max<long long>(1, nobs / m);
   h->nchunks = (int)std::max<long long>(1, std::min<long long>((3072 + m - 1) / m, avg_len / 256));
   // tuning overrides (experiments only)
-  if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(1024, atoi(ev) / 64 * 64));
+  if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(768, atoi(ev) / 64 * 64));
   if (const char *ev = getenv("MVBA_SCHUR_CHUNKS")) h->nchunks = std::max(1, atoi(ev));
   const size_t lds_cap = 150 * 1024;
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
@@ -775,8 +863,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_PB, 10 * N));
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, n9 * n9 + n9));
-  TRY(dmalloc(&h->d_Ared, (size_t)h->D * h->D));
-  TRY(dmalloc(&h->d_bred, h->D));
+  TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
   TRY(dmalloc(&h->d_partials, h->n_partials));
@@ -795,13 +882,14 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   // opt in to large dynamic LDS
   const int strip_lds = (int)((81 * (size_t)h->lseg + 9) * sizeof(double));
-  TRYH(hipFuncSetAttribute((const void *)k_schur_strip, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->D * sizeof(double))));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->D * sizeof(double))));
 #undef TRY
 #undef TRYH
   *out = h;
@@ -815,7 +903,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared,
-                  h->d_bred, h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
+                  h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_flag) hipHostFree(h->h_flag);
@@ -907,7 +995,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
-    hipLaunchKernelGGL(k_schur_strip, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg,
+    auto kern = (h->nobs * 128LL >= (1LL << 32)) ? k_schur_strip<true> : k_schur_strip<false>;
+    hipLaunchKernelGGL(kern, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg,
                        h->d_chunk_ptr, h->d_csc, h->d_cam, h->d_rec, h->d_PB, c, h->f0, d_A, d_b);
   }
   MVBA_HIP(hipGetLastError());
@@ -918,19 +1007,20 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   }
   {
     Timed t(h, MVBA_K_SOLVE);
-    hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D), dim3(256), 0, h->stream, D, m, h->gauge_axis, d_A, d_b,
-                       h->d_Ared, h->d_bred);
+    const int ld = h->ld;
+    hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
+                       h->d_Ared);
     for (int j0 = 0; j0 < D; j0 += NB) {
       const int nb = std::min(NB, D - j0);
-      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb, h->d_flag);
-      const int rem = D - j0 - nb;
-      if (rem > 0) {
-        const int nt = (rem + NB - 1) / NB;
-        hipLaunchKernelGGL(k_chol_panel, dim3(nt), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb);
-        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(NB, NB), 0, h->stream, h->d_Ared, D, j0, nb);
+      const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
+      hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(64), 0, h->stream, h->d_Ared, ld, D, j0, nb,
+                         h->d_flag);
+      if (j0 + nb < D) {
+        const int nt = (rows_below + 63) / 64;
+        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, j0);
       }
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), D * sizeof(double), h->stream, h->d_Ared, D, h->d_bred, m,
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), D * sizeof(double), h->stream, h->d_Ared, ld, D, m,
                        h->gauge_axis, h->d_dxi);
   }
   MVBA_HIP(hipGetLastError());

@@ -1,0 +1,8 @@
+#!/bin/bash
+# PMC passes (separate runs, --kernel-trace only, as the MI355X guide prescribes).
+# usage: tools/pmc_run.sh <tag>
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+tag=$1
+run() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1 || { tail -5 gpurun_out/pmc_${tag}_$name.log; exit 1; }; }
+run fetch FETCH_SIZE && run write WRITE_SIZE && run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES && run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES && run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_*/ 
