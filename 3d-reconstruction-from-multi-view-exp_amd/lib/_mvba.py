@@ -56,8 +56,8 @@ SIGNATURES = {
     "mvba_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mvba_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]),
     "mvba_host_obs_math": (C.c_int, [_dp, _dp, _dp, C.c_double, _dp]),
-    "mvsvd_factorize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mvsvd_factorize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int32]),
 }
 
 _lib = None
@@ -205,3 +205,26 @@ def host_obs_math(X3, cam15, xy2, f0):
     X3, cam15, xy2 = _as(X3, np.float64), _as(cam15, np.float64), _as(xy2, np.float64)
     raise_for(lib.mvba_host_obs_math(_ptr(X3), _ptr(cam15), _ptr(xy2), float(f0), _ptr(out)), lib)
     return out[:2], out[2:8].reshape(2, 3), out[8:].reshape(2, 9)
+
+
+def svd_factorize(Wt, n_rank, center=False, device=-1):
+    """Thin SVD of W = Wt^T through mvsvd_factorize.  Wt: (n_rows, n_cols) float32/float64,
+    C-contiguous.  Returns M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings."""
+    lib = load_library()
+    if device_count() < 1:
+        raise RuntimeError("libmvba: no HIP device visible; the SVD kernel has no CPU fallback")
+    Wt = np.ascontiguousarray(Wt)
+    if Wt.dtype not in (np.float32, np.float64):
+        Wt = Wt.astype(np.float64)
+    n_rows, n_cols = Wt.shape
+    M = np.empty((n_cols, n_rank), Wt.dtype)
+    sigma = np.empty(n_cols, Wt.dtype)
+    S = np.empty((n_rank, n_rows), Wt.dtype)
+    means = np.zeros(n_cols, Wt.dtype)
+    tm = np.zeros(5)
+    rc = lib.mvsvd_factorize(Wt.ctypes.data, n_rows, n_cols, 0 if Wt.dtype == np.float32 else 1, int(n_rank),
+                             int(bool(center)), M.ctypes.data, sigma.ctypes.data, S.ctypes.data, means.ctypes.data,
+                             _ptr(tm), int(device))
+    raise_for(rc, lib)
+    return M, sigma, S, means, {"h2d_ms": tm[0], "gram_ms": tm[1], "jacobi_ms": tm[2], "project_ms": tm[3],
+                                "sweeps": int(tm[4])}

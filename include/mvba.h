@@ -134,10 +134,17 @@ int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2,
  * with n_rows = points (tall) and n_cols = 2m or 3m; the reference's W is Wt^T
  * (perspective_camera_calibration.py:533, affine_camera_calibration.py:236).
  * dtype: 0 = float32, 1 = float64 (outputs have the input dtype, ref quirk B.10).
- * Outputs: M [n_cols][n_rank] (= U[:, :r]), sigma [min(n_cols,..)] first n_rank
- * filled, S [n_rank][n_rows] (= diag(sigma) Vt[:r]).  Thin, never forms Vt.    */
-int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype,
-                    int32_t n_rank, void *M, void *sigma, void *S, int32_t device);
+ * center != 0: subtract the column means of Wt first (= the row means of W the
+ * affine callers remove, affine_camera_calibration.py:224-240); means [n_cols]
+ * receives them (may be NULL).
+ * Outputs: M [n_cols][n_rank] (= U[:, :r]), sigma [n_cols] (all singular values,
+ * descending), S [n_rank][n_rows] (= diag(sigma[:r]) Vt[:r] = M^T W).  Thin: Vt is
+ * never formed.  Sign convention: the largest-magnitude component of every column
+ * of M is positive (LAPACK's signs are not a rule one can restate).
+ * timings_ms (may be NULL) [5]: H2D, Gram, Jacobi, projection (device ms), sweeps. */
+int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank,
+                    int32_t center, void *M, void *sigma, void *S, void *means, double *timings_ms,
+                    int32_t device);
 
 #ifdef __cplusplus
 }

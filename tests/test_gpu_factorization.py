@@ -1,0 +1,95 @@
+"""Parity of the tall-skinny SVD kernels (mvsvd_factorize via lib.factorization.factorization_method)
+with the reference's factorization_method outputs (tests/golden/factorization_24x2000.npz,
+euclid_default.npz: fact_W/M/S captured from the reference).  Singular vectors are defined up to
+sign, so sign-invariant quantities are compared: sigma, the product M @ S and |M^T M_ref|."""
+import numpy as np
+import pytest
+
+from lib import _mvba
+from lib.factorization import factorization_method
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(M, S, M_ref, S_ref, sig, sig_ref, rtol_sigma, atol_prod):
+    r = M.shape[1]
+    np.testing.assert_allclose(sig[:r], sig_ref[:r], rtol=rtol_sigma)
+    # M has orthonormal columns spanning the same subspace as the reference's
+    np.testing.assert_allclose(M.T.astype(np.float64) @ M.astype(np.float64), np.eye(r), atol=50 * atol_prod)
+    np.testing.assert_allclose(np.abs(M.T.astype(np.float64) @ M_ref.astype(np.float64)), np.eye(r), atol=50 * atol_prod)
+    # S = diag(sigma) Vt[:r]  <=>  M @ S is the rank-r part of W, sign free
+    scale = np.abs(M_ref @ S_ref).max()
+    np.testing.assert_allclose(M.astype(np.float64) @ S.astype(np.float64),
+                               M_ref.astype(np.float64) @ S_ref.astype(np.float64), rtol=0, atol=atol_prod * scale)
+
+
+def test_factorization_vs_reference_f64(golden):
+    d = golden("factorization_24x2000")
+    W = d["Wt"].T  # (24, 2000) transposed view, as the callers pass it
+    M, S = factorization_method(W, n_rank=3)
+    assert M.shape == (24, 3) and S.shape == (3, 2000) and M.dtype == np.float64
+    _, sig, _, _, _ = _mvba.svd_factorize(d["Wt"], 3)
+    _check(M, S, d["M_f64"], d["S_f64"], sig, d["sigma_f64"], 1e-11, 1e-11)
+    # default n_rank = 4 (ref factorization.py:6)
+    M4, S4 = factorization_method(W)
+    assert M4.shape == (24, 4) and S4.shape == (4, 2000)
+    _check(M4, S4, d["M4_f64"], d["S4_f64"], sig, d["sigma_f64"], 1e-9, 1e-9)
+    # every singular value, not only the leading ones (noise floor sigma ~ 1e-3 * sqrt(N))
+    np.testing.assert_allclose(sig, d["sigma_f64"], rtol=1e-8)
+
+
+def test_factorization_vs_reference_f32(golden):
+    d = golden("factorization_24x2000")
+    Wt32 = d["Wt"].astype(np.float32)
+    M, S = factorization_method(Wt32.T, n_rank=3)
+    assert M.dtype == np.float32 and S.dtype == np.float32  # output dtype follows the input (ref quirk B.10)
+    _, sig, _, _, _ = _mvba.svd_factorize(Wt32, 3)
+    # judged against the fp64 truth at the tolerance LAPACK fp32 itself achieves
+    _check(M, S, d["M_f64"], d["S_f64"], sig.astype(np.float64), d["sigma_f64"], 1e-6, 1e-5)
+    np.testing.assert_allclose(sig[:3], d["sigma_f32"][:3], rtol=1e-5)
+
+
+def test_perspective_measurement_matrix_rank4(golden):
+    """W (30 x 200) exactly as perspective_self_calibration hands it over (ref :533)."""
+    d = golden("euclid_default")
+    W = d["fact_W"]
+    M, S = factorization_method(np.ascontiguousarray(W.T).T)
+    _, sig, _, _, _ = _mvba.svd_factorize(np.ascontiguousarray(W.T), 4)
+    _check(M, S, d["fact_M"], d["fact_S"], sig, d["fact_sigma"], 1e-10, 1e-10)
+    np.testing.assert_allclose(sig, d["fact_sigma"], rtol=1e-6, atol=1e-12 * d["fact_sigma"][0])
+
+
+@pytest.mark.parametrize("dtype,n_cols", [(np.float32, 24), (np.float64, 24), (np.float32, 200)])
+def test_large_tall_skinny_properties(dtype, n_cols):
+    """BASELINE config 5 shape (rows x 24, fp32) at 1M rows + the optional 200-column variant:
+    size-independent properties against an fp64 LAPACK SVD of the same data."""
+    rng = np.random.default_rng(0)
+    n_rows = 1_000_000 if n_cols == 24 else 200_000
+    A = rng.normal(size=(n_rows, 3))
+    B = rng.normal(size=(3, n_cols))
+    Wt = (A @ B + 1e-3 * rng.normal(size=(n_rows, n_cols))).astype(dtype)
+    M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 3)
+    sig_ref = np.linalg.svd(Wt.astype(np.float64), compute_uv=False)
+    tol = 1e-6 if dtype == np.float32 else 1e-11
+    np.testing.assert_allclose(sig[:3].astype(np.float64), sig_ref[:3], rtol=tol)
+    M64, S64 = M.astype(np.float64), S.astype(np.float64)
+    np.testing.assert_allclose(M64.T @ M64, np.eye(3), atol=1e-5 if dtype == np.float32 else 1e-12)
+    # S = M^T W exactly (that is how diag(sigma) Vt[:r] is produced), rows of S orthogonal with norms sigma
+    np.testing.assert_allclose(S64, M64.T @ Wt.astype(np.float64).T, rtol=0,
+                               atol=(1e-4 if dtype == np.float32 else 1e-10) * np.abs(S64).max())
+    np.testing.assert_allclose(np.linalg.norm(S64, axis=1), sig_ref[:3], rtol=10 * tol)
+    # rank-3 reconstruction error = the discarded singular values
+    resid = Wt[:20000].astype(np.float64) - (M64 @ S64[:, :20000]).T
+    assert np.abs(resid).max() < 1e-2
+    assert tm["sweeps"] < 30
+    # centring (affine callers, ref affine_camera_calibration.py:224-240)
+    Mc, sigc, Sc, muc, _ = _mvba.svd_factorize(Wt, 3, center=True)
+    W64 = Wt.astype(np.float64)
+    np.testing.assert_allclose(muc.astype(np.float64), W64.mean(axis=0), rtol=0, atol=1e-5 if dtype == np.float32 else 1e-12)
+    sig_c_ref = np.linalg.svd(W64 - W64.mean(axis=0), compute_uv=False)
+    np.testing.assert_allclose(sigc[:3].astype(np.float64), sig_c_ref[:3], rtol=tol)
+
+
+def test_bad_arguments():
+    with pytest.raises(ValueError):
+        _mvba.svd_factorize(np.zeros((10, 4)), 5)
