@@ -215,3 +215,37 @@ def test_profiling_stats_are_populated():
     for k in ("resid_jac", "point_blocks", "point_inv", "schur", "solve", "backsub_cost"):
         assert st[k]["launches"] >= 1 and st[k]["ms"] > 0, k
     assert st["counts"]["linearize"] == 1 and st["counts"]["try_step"] == 1
+
+
+def test_virtual_point_shards_sum_to_the_full_reduced_system():
+    """the partial [A|b] of point shards add up to the unsharded one (what the
+    RCCL all-reduce exchanges), and a size-1 RCCL communicator changes nothing."""
+    from lib import _distributed as D
+
+    sc = make_scene(6000, 9, vis_p=0.5)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    f, u = sc.init_K[:, 0, 0], sc.init_K[:, :2, 2]
+
+    def engine(lo, hi, comm=False):
+        p, c, x = D.slice_observations(sc.pt_ptr, sc.cam_idx, sc.xy, lo, hi)
+        e = _mvba.HipEngine(hi - lo, 9, p, c, x, 1.0, sc.axis)
+        if comm:
+            e.comm_init(_mvba.comm_unique_id(), 0, 1)
+        e.set_params(X[lo:hi], f, u, t, R)
+        e.linearize()
+        return e, e.try_step(1e-4)
+
+    full, E_full = engine(0, sc.n_points)
+    A, b = full.debug_read("A_full"), full.debug_read("b_full")
+    As, bs, Es = np.zeros_like(A), np.zeros_like(b), 0.0
+    for lo, hi in D.partition_points(sc.pt_ptr, 3):
+        e, _ = engine(lo, hi)
+        As += e.debug_read("A_full")
+        bs += e.debug_read("b_full")
+    np.testing.assert_allclose(As, A, rtol=0, atol=1e-12 * np.abs(A).max())
+    np.testing.assert_allclose(bs, b, rtol=0, atol=1e-10 * np.abs(b).max())
+    withc, E_c = engine(0, sc.n_points, comm=True)
+    assert E_c == pytest.approx(E_full, rel=1e-12)
+    # two runs differ by the order of the Schur atomics: eps x cond(A) on the solution
+    np.testing.assert_allclose(withc.debug_read("dxi"), full.debug_read("dxi"), rtol=0, atol=1e-9 * np.abs(full.debug_read("dxi")).max())
+    assert withc.cost() == pytest.approx(full.cost(), rel=1e-13)
