@@ -33,6 +33,44 @@ for p in (PKG, ROOT):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_k1_config3.json")
+
+
+def pmc_traffic(n_obs):
+    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes of THIS workload
+    (tools/pmc_run.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)."""
+    try:
+        d = json.load(open(PMC_FILE))
+        if int(d["n_obs"]) != int(n_obs):
+            return None
+        return (2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024.0
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def svd_config5(rows, cols=24):
+    """BASELINE config 5: rows x 24 fp32 measurement-matrix SVD (rank 3) on the GPU; device times
+    from hipEvents inside mvsvd_factorize, HBM-resident (H2D excluded, reported separately)."""
+    from lib import _mvba
+
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((rows, 3), dtype=np.float32)
+    B = rng.standard_normal((3, cols), dtype=np.float32)
+    Wt = A @ B + np.float32(1e-3) * rng.standard_normal((rows, cols), dtype=np.float32)
+    _mvba.svd_factorize(Wt[:100000], 3)  # warm-up (module load)
+    M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 3)
+    dev_ms = tm["gram_ms"] + tm["jacobi_ms"] + tm["project_ms"]
+    alg = 2 * rows * cols * 4 + 3 * rows * 4
+    n_cpu = min(rows, 500_000)
+    t0 = time.perf_counter()
+    np.linalg.svd(Wt[:n_cpu], full_matrices=False)
+    cpu_s = (time.perf_counter() - t0) * rows / n_cpu
+    return {"workload": f"{rows} x {cols} fp32, rank 3", "device_ms": dev_ms, "h2d_ms": tm["h2d_ms"],
+            "gram_ms": tm["gram_ms"], "jacobi_ms": tm["jacobi_ms"], "project_ms": tm["project_ms"],
+            "algorithmic_bytes": alg, "achieved_GBs": alg / (dev_ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cpu_numpy_thin_svd_s": cpu_s, "cpu_sample_rows": n_cpu, "sigma": [float(x) for x in sig[:4]]}
 
 
 def cpu_baseline(n_points_full, n_images, vis_p, n_obs_full, sample_points):
@@ -77,6 +115,7 @@ def main():
     ap.add_argument("--vis", type=float, default=0.1)
     ap.add_argument("--cpu-sample-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -160,13 +199,15 @@ def main():
             "inner_solves": eng.n_solves - solves0,
             "rmse_start": float(np.sqrt(E0 / n_obs_total)), "rmse_end": rmse,
             "roofline": {"kernel": "k_resid_jac", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(sc.n_obs),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_total, args.cams, args.vis, n_obs_total,
                                                min(args.cpu_sample_points, args.points))
+            if args.svd_rows > 0:
+                out["factorization_svd_config5"] = svd_config5(args.svd_rows)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
