@@ -177,7 +177,10 @@ def main():
     if rank == 0:
         k1 = st["resid_jac"]
         k1_ms = k1["ms"] / max(k1["launches"], 1)
-        alg_bytes = 232 * sc.n_obs + 24 * sc.n_points  # per launch, this rank
+        # K1 algorithmic bytes per launch on this rank: in xy 16 + cam 4 + point id 4,
+        # out ONE 128-B record per observation (the 2x9 block's t and (u,v) columns are implied),
+        # + 24 B per point.  (SURVEY 8d's 232 B/obs assumed the 208-B materialised 2x9 form.)
+        alg_bytes = 152 * sc.n_obs + 24 * sc.n_points
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         rmse = float(np.sqrt(E_ / n_obs_total))
         out = {
@@ -200,10 +203,12 @@ def main():
             "rmse_start": float(np.sqrt(E0 / n_obs_total)), "rmse_end": rmse,
             "roofline": {"kernel": "k_resid_jac", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(sc.n_obs),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms},
+                         "traffic_unit": "bytes per launch (PMC)", "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_obs": 152, "avg_launch_ms": k1_ms},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
         }
         if not args.no_cpu_baseline:
+            eng.close()
             out["cpu_baseline"] = cpu_baseline(n_total, args.cams, args.vis, n_obs_total,
                                                min(args.cpu_sample_points, args.points))
             if args.svd_rows > 0:
