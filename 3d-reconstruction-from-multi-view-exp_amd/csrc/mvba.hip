@@ -255,9 +255,8 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     double kx00 = qk[0], kx10 = qk[1], kx01 = qk[2], kx11 = qk[3], kx02 = qk[4], kx12 = qk[5];
     double kf0 = qk[6], kf1 = qk[7];
     double kw00 = qk[8], kw10 = qk[9], kw01 = qk[10], kw11 = qk[11], kw02 = qk[12], kw12 = qk[13];
-    double ke0 = qk[14], ke1 = qk[15];
     double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
-    double v0 = pb[6], v1 = pb[7], v2 = pb[8];
+    const double *PBg = PB;
     // l-side of the first pass
     bool act = slot < cur.z;
     int ol = cur.x + (act ? slot : 0);
@@ -305,8 +304,11 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           gg[8] = kw02 * d0 + kw12 * d1;
 #pragma unroll
           for (int i = 0; i < 9; ++i) val[i] += (i == j) ? gg[i] * damp : gg[i];
-          const double w0 = kx00 * v0 + kx01 * v1 + kx02 * v2 - ke0;
-          const double w1 = kx10 * v0 + kx11 * v1 + kx12 * v2 - ke1;
+          // rare path (one item per entry): E^-1 dP of the point and the residual, per-lane loads
+          const double *pv = PBg + 10 * (size_t)cur.y + 6;
+          const double2 ke = *reinterpret_cast<const double2 *>(line(cur.x) + 112);
+          const double w0 = kx00 * pv[0] + kx01 * pv[1] + kx02 * pv[2] - ke.x;
+          const double w1 = kx10 * pv[0] + kx11 * pv[1] + kx12 * pv[2] - ke.y;
           bval = d0 * w0 + d1 * w1;
         }
       }
@@ -327,9 +329,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           kx00 = qk[0]; kx10 = qk[1]; kx01 = qk[2]; kx11 = qk[3]; kx02 = qk[4]; kx12 = qk[5];
           kf0 = qk[6]; kf1 = qk[7];
           kw00 = qk[8]; kw10 = qk[9]; kw01 = qk[10]; kw11 = qk[11]; kw02 = qk[12]; kw12 = qk[13];
-          ke0 = qk[14]; ke1 = qk[15];
           i00 = pb[0]; i01 = pb[1]; i02 = pb[2]; i11 = pb[3]; i12 = pb[4]; i22 = pb[5];
-          v0 = pb[6]; v1 = pb[7]; v2 = pb[8];
         }
       }
       if (!done) {

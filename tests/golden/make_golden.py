@@ -331,6 +331,67 @@ def small_known_answers():
     )
 
 
+def calibration_vectors():
+    """Callers either side of the hot path: affine self-calibration
+    (three camera models) and perspective self-calibration (primary / dual projective depths),
+    on the default scenes' observations."""
+    from lib.affine_camera_calibration import (
+        _get_observation_matrix,
+        orthographic_self_calibration,
+        paraperspective_self_calibration,
+        symmetric_affine_self_calibration,
+    )
+    from lib import perspective_camera_calibration as pc
+
+    d = np.load(os.path.join(HERE, "affine_default.npz"))
+    x_list = [a.copy() for a in d["x_noisy"]]  # 12 x (200,2)
+    W, t = _get_observation_matrix([a.copy() for a in x_list])
+    U, Sig, Vt = np.linalg.svd(W)
+    out = {"aff_x": np.stack(x_list), "aff_W": W, "aff_t": t, "aff_U3": U[:, :3], "aff_sigma": Sig,
+           "aff_Vt3": Vt[:3]}
+    Xo, Ro = orthographic_self_calibration([a.copy() for a in x_list])
+    Xs, Rs = symmetric_affine_self_calibration([a.copy() for a in x_list])
+    Xp, Rp = paraperspective_self_calibration([a.copy() for a in x_list], 1.0 * np.ones(12))
+    Xp2, Rp2 = paraperspective_self_calibration([a.copy() for a in x_list], np.linspace(0.8, 1.3, 12))
+    out.update(ortho_X=Xo, ortho_R=Ro, symaff_X=Xs, symaff_R=Rs, para_X=Xp, para_R=Rp, para2_X=Xp2, para2_R=Rp2,
+               para2_f=np.linspace(0.8, 1.3, 12))
+
+    e = np.load(os.path.join(HERE, "euclid_default.npz"))
+    xe = [e["x"][:, k, :].copy() for k in range(e["x"].shape[1])]  # 10 x (200,2), noisy
+    xm = pc._create_data_matrix(xe, 1.0)
+    for method, fn in (("primary", pc._compute_projective_depth_primary_method),
+                       ("dual", pc._compute_projective_depth_dual_method)):
+        z, txt = _quiet(fn, xm, 1.0, 1e-2)
+        (X, R, t_, K), txt2 = _quiet(pc.perspective_self_calibration, [a.copy() for a in xe], 1.0, tol=1e-2, method=method)
+        out.update({f"persp_{method}_z": z, f"persp_{method}_stdout": np.array(txt),
+                    f"persp_{method}_X": X, f"persp_{method}_R": R, f"persp_{method}_t": t_, f"persp_{method}_K": K})
+        Wm = xm * z[..., np.newaxis]
+        Wf = Wm.reshape(Wm.shape[0], -1).T
+        M, S = factorization_method(Wf)
+        P = M.reshape(-1, 3, 4)
+        H, Kk = pc._euclidean_upgrading(P, 1.0)
+        X3, R3, t3 = pc._reconstruct_3d(P, S, Kk, H)
+        # one well-posed step of the upgrade loop (the loop itself is chaotic for the primary
+        # depths on this scene: J_med = 1.9e9 after the first step)
+        K0 = np.tile(np.eye(3), (P.shape[0], 1, 1))
+        Q0 = np.linalg.inv(K0) @ P
+        Om1, sig1, w1 = pc._calc_omega(Q0)
+        K1, J1 = pc._update_K(K0.copy(), Om1, Q0)
+        out.update({f"persp_{method}_Omega1": Om1, f"persp_{method}_sigma1": sig1, f"persp_{method}_K1": K1,
+                    f"persp_{method}_J1": J1})
+        out.update({f"persp_{method}_M": M, f"persp_{method}_S": S, f"persp_{method}_H": H, f"persp_{method}_Kup": Kk,
+                    f"persp_{method}_X3": X3, f"persp_{method}_R3": R3, f"persp_{method}_t3": t3})
+    out["persp_x"] = np.stack(xe)
+    # three forced iterations of each projective-depth scheme (tolerance 0 never met)
+    z3p, _ = _quiet(pc._compute_projective_depth_primary_method, xm, 1.0, 0.0, 3)
+    z3d, _ = _quiet(pc._compute_projective_depth_dual_method, xm, 1.0, 0.0, 3)
+    out.update(persp_primary_z3=z3p, persp_dual_z3=z3d)
+    Xc, Rc, tc = pc.correct_world_coordinates(out["persp_dual_X3"], out["persp_dual_R3"], out["persp_dual_t3"],
+                                              method="first_camera")
+    out.update(first_cam_X=Xc, first_cam_R=Rc, first_cam_t=tc)
+    _save("calibration", **out)
+
+
 if __name__ == "__main__":
     euclid_default()
     affine_default()
@@ -339,3 +400,4 @@ if __name__ == "__main__":
     visibility_scene()
     factorization_vectors()
     small_known_answers()
+    calibration_vectors()
