@@ -225,7 +225,6 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
   const double beta_x = (j == 1) ? 4.0 * cu : 0.0, beta_y = (j == 2) ? 4.0 * cu : 0.0;
   const long long beg = chunk_ptr[(size_t)k * (nchunks + 1) + chunk];
   const long long end = chunk_ptr[(size_t)k * (nchunks + 1) + chunk + 1];
-  const double damp = 1.0 + c;
   // scalar views (plain int / double elements: HIP vector types do not cross address spaces)
   const auto *csc_c = as_const(reinterpret_cast<const int *>(csc));
   const auto *rec_c = as_const(reinterpret_cast<const double *>(rec));
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       const bool valid = act && slot < 7 && l >= l_lo && l < l_hi;
       double *dst = strip + (9 * (l - l_lo) + j) * 9;
       const bool diag = valid && (base + slot == 0);
-      double val[9], bval = 0.0;
+      double val[9], bval = 0.0, dval = 0.0;
       {
         const double cjx = alpha * cs.x + beta_x, cjy = alpha * cs.y + beta_y;  // 4 * Jc_l[:, j]
         const double g0 = x0.x * cjx + x0.y * cjy;  // 2 * F_al[:, j]
@@ -278,8 +277,22 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
         const double h0 = i00 * g0 + i01 * g1 + i02 * g2;  // 2 * E^-1 F_al[:, j]
         const double h1 = i01 * g0 + i11 * g1 + i12 * g2;
         const double h2 = i02 * g0 + i12 * g1 + i22 * g2;
-        const double t0 = kx00 * h0 + kx01 * h1 + kx02 * h2;  // 2 Jx_k E^-1 F_al[:, j]
-        const double t1 = kx10 * h0 + kx11 * h1 + kx12 * h2;
+        double t0 = kx00 * h0 + kx01 * h1 + kx02 * h2;  // 2 Jx_k E^-1 F_al[:, j]
+        double t1 = kx10 * h0 + kx11 * h1 + kx12 * h2;
+        if (diag) {
+          // diagonal item (l == k, Jc_l == Jc_k): G_k - S_kk = -Jc_k^T (t - 2 Jc_k[:, j]); the
+          // Marquardt factor (1+c) on G's diagonal is one extra accumulation on element (j, j);
+          // right-hand side 2 Jc_k[:, j] . (Jx_k E^-1 dP - e).  Rare operands come per lane.
+          const double d0 = 0.5 * cjx, d1 = 0.5 * cjy;  // 2 * Jc_k[:, j]
+          t0 -= d0;
+          t1 -= d1;
+          dval = c * 0.125 * (cjx * cjx + cjy * cjy);  // c * 2 |Jc_k[:, j]|^2
+          const double *pv = PBg + 10 * (size_t)cur.y + 6;
+          const double2 ke = *reinterpret_cast<const double2 *>(line(cur.x) + 112);
+          const double w0 = kx00 * pv[0] + kx01 * pv[1] + kx02 * pv[2] - ke.x;
+          const double w1 = kx10 * pv[0] + kx11 * pv[1] + kx12 * pv[2] - ke.y;
+          bval = d0 * w0 + d1 * w1;
+        }
         // -(Jc_k[:, i] . t) for i = f, u, v, t(3), omega(3)   (t columns of Jc are -Jx)
         val[0] = -(kf0 * t0 + kf1 * t1);
         val[1] = -(cu * t0);
@@ -290,27 +303,6 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
         val[6] = -(kw00 * t0 + kw10 * t1);
         val[7] = -(kw01 * t0 + kw11 * t1);
         val[8] = -(kw02 * t0 + kw12 * t1);
-        if (diag) {  // diagonal item (l == k): + G^_k and the right-hand side
-          const double d0 = 0.5 * cjx, d1 = 0.5 * cjy;  // 2 * Jc_k[:, j]
-          double gg[9];
-          gg[0] = kf0 * d0 + kf1 * d1;
-          gg[1] = cu * d0;
-          gg[2] = cu * d1;
-          gg[3] = -(kx00 * d0 + kx10 * d1);
-          gg[4] = -(kx01 * d0 + kx11 * d1);
-          gg[5] = -(kx02 * d0 + kx12 * d1);
-          gg[6] = kw00 * d0 + kw10 * d1;
-          gg[7] = kw01 * d0 + kw11 * d1;
-          gg[8] = kw02 * d0 + kw12 * d1;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) val[i] += (i == j) ? gg[i] * damp : gg[i];
-          // rare path (one item per entry): E^-1 dP of the point and the residual, per-lane loads
-          const double *pv = PBg + 10 * (size_t)cur.y + 6;
-          const double2 ke = *reinterpret_cast<const double2 *>(line(cur.x) + 112);
-          const double w0 = kx00 * pv[0] + kx01 * pv[1] + kx02 * pv[2] - ke.x;
-          const double w1 = kx10 * pv[0] + kx11 * pv[1] + kx12 * pv[2] - ke.y;
-          bval = d0 * w0 + d1 * w1;
-        }
       }
       // ---------------- advance to pass n+1 and issue its loads
       bool done = false;
@@ -349,7 +341,10 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       if (valid) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) atomicAdd(dst + i, val[i]);
-        if (diag) atomicAdd(&sb[j], bval);
+        if (diag) {
+          atomicAdd(dst + j, dval);  // (1+c) damping of G_k's diagonal (ref :123-125)
+          atomicAdd(&sb[j], bval);
+        }
       }
       if (done) break;
     }
