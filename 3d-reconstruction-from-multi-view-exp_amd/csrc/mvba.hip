@@ -71,7 +71,10 @@ __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
 // One thread per observation, grid-stride over 256-observation tiles; camera table
 // staged once per block.  Each wave transposes its 64 records through LDS so that
 // every global store instruction writes 1 KiB contiguous (8 whole lines).
-// Algorithmic traffic: 24 B in + 128 B out per observation + 24 B per point.
+// K2 is fused in: the per-point blocks E_a = 2 sum Jx^T Jx (6 unique) and dP_a = 2 sum Jx^T e
+// (ref :429-469, :519-556) are formed by a wave-level segmented sum over the (point-sorted)
+// observations -- PL[a][9] = Exx,Exy,Exz,Eyy,Eyz,Ezz,dP0..2 -- so the records are not re-read.
+// Algorithmic traffic: 24 B in + 128 B out per observation + (24 in + 72 out) B per point.
 constexpr int REC = 8;  // double2 slots per observation record (128 B)
 
 __global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
@@ -79,20 +82,27 @@ __global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const 
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
                                                    const double2 *__restrict__ xy, double f0,
-                                                   double2 *__restrict__ rec) {
+                                                   double2 *__restrict__ rec, double *__restrict__ PL) {
   extern __shared__ double smem[];
   double *s_cam = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
   double2 *stage = reinterpret_cast<double2 *>(smem + ((m * CAM_LDS + 1) & ~1)) + wave * (64 * REC);
+  // the same 8 KiB is reused for the per-point sums: contrib[9][64] doubles, then seg_start[65], pt[64]
+  double *contrib = reinterpret_cast<double *>(stage);
+  int *seg_start = reinterpret_cast<int *>(contrib + 9 * 64), *seg_pt = seg_start + 66;
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long base = (long long)blockIdx.x * blockDim.x; base < nobs; base += stride) {
     const long long wbase = base + 64 * wave;  // first observation of this wave's tile
     const long long o = wbase + lane;
-    if (o < nobs) {
-      const int a = obs_pt[o], k = cam_idx[o];
+    const bool live = o < nobs;
+    int a = -1;
+    double c9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      a = obs_pt[o];
+      const int k = cam_idx[o];
       const double2 z = xy[o];
       const double *Xa = X + 3 * (size_t)a;
       ObsJ J;
@@ -108,6 +118,16 @@ __global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const 
       row[5 ^ sw] = make_double2(J.jc[0][7], J.jc[1][7]);
       row[6 ^ sw] = make_double2(J.jc[0][8], J.jc[1][8]);
       row[7 ^ sw] = make_double2(J.e0, J.e1);
+      // K2 fused: this observation's share of E_a = 2 sum Jx^T Jx and dP_a = 2 sum Jx^T e
+      c9[0] = 2.0 * (J.jx[0][0] * J.jx[0][0] + J.jx[1][0] * J.jx[1][0]);
+      c9[1] = 2.0 * (J.jx[0][0] * J.jx[0][1] + J.jx[1][0] * J.jx[1][1]);
+      c9[2] = 2.0 * (J.jx[0][0] * J.jx[0][2] + J.jx[1][0] * J.jx[1][2]);
+      c9[3] = 2.0 * (J.jx[0][1] * J.jx[0][1] + J.jx[1][1] * J.jx[1][1]);
+      c9[4] = 2.0 * (J.jx[0][1] * J.jx[0][2] + J.jx[1][1] * J.jx[1][2]);
+      c9[5] = 2.0 * (J.jx[0][2] * J.jx[0][2] + J.jx[1][2] * J.jx[1][2]);
+      c9[6] = 2.0 * (J.jx[0][0] * J.e0 + J.jx[1][0] * J.e1);
+      c9[7] = 2.0 * (J.jx[0][1] * J.e0 + J.jx[1][1] * J.e1);
+      c9[8] = 2.0 * (J.jx[0][2] * J.e0 + J.jx[1][2] * J.e1);
     }
     __builtin_amdgcn_wave_barrier();  // wave-synchronous hand-over through LDS (in-order DS queue)
 #pragma unroll
@@ -118,34 +138,34 @@ __global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const 
       if (og < nobs) rec[og * REC + (pos ^ (ol & 7))] = v;
     }
     __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ------------------------------------------------------------------ K2
-// One thread per point: E_a (6 unique), dP_a (3).  PL[a][9] = Exx,Exy,Exz,Eyy,Eyz,Ezz,dP0..2
-__global__ __launch_bounds__(256) void k_point_blocks(long long npts, const long long *__restrict__ pt_ptr,
-                                                      const double2 *__restrict__ rec, double *__restrict__ PL) {
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= npts) return;
-  double E[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-  for (long long o = pt_ptr[a]; o < pt_ptr[a + 1]; ++o) {
-    const double2 *q = rec + o * REC;
-    const double2 x0 = q[0], x1 = q[1], x2 = q[2], r = q[7];
-    E[0] += x0.x * x0.x + x0.y * x0.y;
-    E[1] += x0.x * x1.x + x0.y * x1.y;
-    E[2] += x0.x * x2.x + x0.y * x2.y;
-    E[3] += x1.x * x1.x + x1.y * x1.y;
-    E[4] += x1.x * x2.x + x1.y * x2.y;
-    E[5] += x2.x * x2.x + x2.y * x2.y;
-    g[0] += x0.x * r.x + x0.y * r.y;
-    g[1] += x1.x * r.x + x1.y * r.y;
-    g[2] += x2.x * r.x + x2.y * r.y;
-  }
-  double *out = PL + 9 * a;
+    // ---- per-point sums (wave-level segmented reduction; observations are sorted by point)
+    const int a_prev = __shfl_up(a, 1, 64);
+    const bool head = live && (lane == 0 || a != a_prev);
+    const unsigned long long heads = __ballot(head);
+    const int nseg = __popcll(heads);
+    const int nlive = __popcll(__ballot(live));
 #pragma unroll
-  for (int i = 0; i < 6; ++i) out[i] = 2.0 * E[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) out[6 + i] = 2.0 * g[i];
+    for (int q = 0; q < 9; ++q) contrib[q * 64 + lane] = c9[q];
+    if (head) {
+      const int rank = __popcll(heads & ((1ull << lane) - 1ull));
+      seg_start[rank] = lane;
+      seg_pt[rank] = a;
+    }
+    if (lane == 0) seg_start[nseg] = nlive;
+    __builtin_amdgcn_wave_barrier();
+    const int sl = lane / 9, comp = lane - 9 * sl;
+    for (int s0 = 0; s0 < nseg; s0 += 7) {
+      const int sg = s0 + sl;
+      if (sl < 7 && sg < nseg) {
+        const int i0 = seg_start[sg], i1 = seg_start[sg + 1];
+        double acc = 0.0;
+        for (int i = i0; i < i1; ++i) acc += contrib[comp * 64 + i];
+        // a point's observations may straddle two tiles: PL is zero-filled, partial sums add up
+        atomicAdd(&PL[9 * (size_t)seg_pt[sg] + comp], acc);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ------------------------------------------------------------------ K3a
@@ -956,17 +976,13 @@ int mvba_linearize(mvba_handle *h) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
   MVBA_HIP(hipSetDevice(h->device));
+  MVBA_HIP(hipMemsetAsync(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(h->N, 1), h->stream));
   if (h->nobs) {
-    Timed t(h, MVBA_K_RESID_JAC);
+    Timed t(h, MVBA_K_RESID_JAC);  // K1 with K2 (per-point blocks) fused in
     const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double);
     const int grid = (int)std::min<long long>(2048, (h->nobs + 255) / 256);
     hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(256), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
-                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_rec);
-  }
-  if (h->N) {
-    Timed t(h, MVBA_K_POINT_BLOCKS);
-    hipLaunchKernelGGL(k_point_blocks, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N,
-                       h->d_pt_ptr, h->d_rec, h->d_PL);
+                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_rec, h->d_PL);
   }
   MVBA_HIP(hipGetLastError());
   h->linearized = true; h->have_trial = false;

@@ -179,8 +179,9 @@ def main():
         k1_ms = k1["ms"] / max(k1["launches"], 1)
         # K1 algorithmic bytes per launch on this rank: in xy 16 + cam 4 + point id 4,
         # out ONE 128-B record per observation (the 2x9 block's t and (u,v) columns are implied),
-        # + 24 B per point.  (SURVEY 8d's 232 B/obs assumed the 208-B materialised 2x9 form.)
-        alg_bytes = 152 * sc.n_obs + 24 * sc.n_points
+        # + per point 24 B in (X) and 72 B out (E_a, dP_a: K2 is fused into K1).
+        # (SURVEY 8d's 232 B/obs assumed the 208-B materialised 2x9 form and a separate K2.)
+        alg_bytes = 152 * sc.n_obs + 96 * sc.n_points
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         rmse = float(np.sqrt(E_ / n_obs_total))
         out = {

@@ -54,7 +54,7 @@ typedef struct mvba_problem {
 /* Kernel ids for mvba_stats (names via mvba_kernel_name). */
 enum {
   MVBA_K_RESID_JAC = 0, /* K1 residual + 2x3 / 2x9 Jacobians   (ref :291-427)            */
-  MVBA_K_POINT_BLOCKS,  /* K2 E_a, dP_a                         (ref :429-469, :519-556)  */
+  MVBA_K_POINT_BLOCKS,  /* K2 E_a, dP_a (ref :429-469, :519-556): fused into K1, always 0 */
   MVBA_K_POINT_INV,     /* K3a damped 3x3 inverse, E^-1 dP      (ref :120-128)            */
   MVBA_K_SCHUR,         /* K3 A = G^ - sum F^T E^-1 F, b        (ref :132-143, :471-517, :618-664) */
   MVBA_K_ALLREDUCE,     /* C1 RCCL all-reduce of [A|b]                                    */
