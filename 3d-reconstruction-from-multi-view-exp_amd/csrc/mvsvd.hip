@@ -23,44 +23,111 @@ using namespace mvba;
 
 namespace {
 
-constexpr int GT = 32;  // Gram output tile (GT x GT per block), 256 threads = 16x16 with 2x2 each
-constexpr int GR = 32;  // rows staged per step
+constexpr int GT = 16;             // Gram tile = one v_mfma_f64_16x16x4_f64 accumulator
+constexpr int ROWS_PER_STEP = 32;  // rows consumed per unrolled step (8 MFMA k-groups of 4 rows)
+typedef double svd_d4 __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_gram(const T *__restrict__ Wt, long long n_rows, int n, int n_tiles,
-                                              double *__restrict__ G) {
-  // blockIdx.x enumerates upper tile pairs (ti <= tj); blockIdx.y strides over row chunks
-  int ti = 0, rem = blockIdx.x;
-  while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
-  const int tj = ti + rem;
-  __shared__ double As[GR][GT + 1], Bs[GR][GT + 1];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double acc[2][2] = {{0, 0}, {0, 0}};
-  const long long step = (long long)gridDim.y * GR;
-  for (long long r0 = (long long)blockIdx.y * GR; r0 < n_rows; r0 += step) {
-    for (int q = threadIdx.x; q < GR * GT; q += 256) {
-      const int rr = q / GT, cc = q % GT;
-      const long long row = r0 + rr;
-      const int ca = ti * GT + cc, cb = tj * GT + cc;
-      As[rr][cc] = (row < n_rows && ca < n) ? (double)Wt[row * n + ca] : 0.0;
-      Bs[rr][cc] = (row < n_rows && cb < n) ? (double)Wt[row * n + cb] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int rr = 0; rr < GR; ++rr) {
-      const double a0 = As[rr][ty], a1 = As[rr][ty + 16], b0 = Bs[rr][tx], b1 = Bs[rr][tx + 16];
-      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1;
-      acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-    }
-    __syncthreads();
+// G += Wt^T Wt on the f64 matrix cores.  For 4 consecutive rows r0..r3 and column tiles (ti,tj):
+//   A[i][k] = Wt[r_k][16 ti + i]   (lane l: i = l & 15, k = l >> 4)
+//   B[k][j] = Wt[r_k][16 tj + j]   (lane l: k = l >> 4, j = l & 15)
+// so both operands are "this lane's row (l >> 4), this lane's column (l & 15) of a tile": one
+// value per lane per tile, converted to fp64 on load.  C/D: col = l & 15, row = (l >> 4) + 4 reg.
+// Partial tiles go to partial[chunk][pair][256] (no atomics: millions of f64 adds onto a
+// 24 x 24 matrix serialise at the memory side); k_gram_reduce sums the chunks in fixed order.
+__device__ __forceinline__ void gram_store_partial(const svd_d4 *acc, int npairs, int pair0, int pairs_total,
+                                                   double *__restrict__ partial) {
+  __shared__ double red[4][3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = 0; q < npairs; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][q][r][lane] = acc[q][r];
+  __syncthreads();
+  double *out = partial + ((size_t)blockIdx.y * pairs_total + pair0) * 256;
+  for (int e = threadIdx.x; e < npairs * 256; e += 256) {
+    const int q = e >> 8, r = (e >> 6) & 3, l = e & 63;
+    out[e] = red[0][q][r][l] + red[1][q][r][l] + red[2][q][r][l] + red[3][q][r][l];
   }
+}
+
+// n <= 16 * NT (NT = 1 or 2): one pass over the rows forms every tile pair (1 or 3 MFMAs per 4 rows)
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, long long n_rows, int n,
+                                                    double *__restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int NP = NT * (NT + 1) / 2;
+  svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  int col[NT];
+  bool cok[NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < NT; ++t) { cok[t] = GT * t + li < n; col[t] = min(GT * t + li, n - 1); }
+  const long long stride = (long long)gridDim.y * 4 * ROWS_PER_STEP;
+  for (long long r0 = ((long long)blockIdx.y * 4 + wave) * ROWS_PER_STEP; r0 < n_rows; r0 += stride) {
+    double v[ROWS_PER_STEP / 4][NT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int gi = ti * GT + ty + 16 * i, gj = tj * GT + tx + 16 * j;
-      if (gi < n && gj < n) atomicAdd(&G[(size_t)gi * n + gj], acc[i][j]);
+    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {  // all loads of the step first (clamped, branch-free)
+      const long long row = r0 + 4 * g + lk;
+      const T *wr = Wt + min(row, n_rows - 1) * n;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double x = (double)wr[col[t]];
+        v[g][t] = (row < n_rows && cok[t]) ? x : 0.0;
+      }
     }
+#pragma unroll
+    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
+      int q = 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[g][t], v[g][u], acc[q], 0, 0, 0);
+    }
+  }
+  gram_store_partial(acc, NP, 0, NP, partial);
+}
+
+// larger n: blockIdx.x = one upper tile pair (the rows are re-read once per pair, from L2 / MALL)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, long long n_rows, int n, int n_tiles,
+                                                   int n_pairs, double *__restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  int ti = 0, pr = blockIdx.x;
+  while (pr >= n_tiles - ti) { pr -= n_tiles - ti; ++ti; }
+  const int tj = ti + pr;
+  const bool aok = GT * ti + li < n, bok = GT * tj + li < n;
+  const int ca = min(GT * ti + li, n - 1), cb = min(GT * tj + li, n - 1);
+  svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  const long long stride = (long long)gridDim.y * 4 * ROWS_PER_STEP;
+  for (long long r0 = ((long long)blockIdx.y * 4 + wave) * ROWS_PER_STEP; r0 < n_rows; r0 += stride) {
+    double va[ROWS_PER_STEP / 4], vb[ROWS_PER_STEP / 4];
+#pragma unroll
+    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
+      const long long row = r0 + 4 * g + lk;
+      const T *wr = Wt + min(row, n_rows - 1) * n;
+      const double xa = (double)wr[ca], xb = (double)wr[cb];
+      va[g] = (row < n_rows && aok) ? xa : 0.0;
+      vb[g] = (row < n_rows && bok) ? xb : 0.0;
+    }
+#pragma unroll
+    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[g], vb[g], acc[0], 0, 0, 0);
+  }
+  gram_store_partial(acc, 1, blockIdx.x, n_pairs, partial);
+}
+
+// G[gi][gj] = sum over row chunks of the partial tiles (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int chunks, int n, int n_tiles,
+                                                     int n_pairs, double *__restrict__ G) {
+  int ti = 0, pr = blockIdx.x;
+  while (pr >= n_tiles - ti) { pr -= n_tiles - ti; ++ti; }
+  const int tj = ti + pr;
+  const int e = threadIdx.x, r = (e >> 6) & 3, l = e & 63;
+  double sacc = 0.0;  // gridDim.y slices of the chunk range, 8 independent loads in flight
+  const int c0 = (int)((long long)chunks * blockIdx.y / gridDim.y), c1 = (int)((long long)chunks * (blockIdx.y + 1) / gridDim.y);
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) sacc += partial[((size_t)c * n_pairs + blockIdx.x) * 256 + e];
+  const int gi = GT * ti + (l >> 4) + 4 * r, gj = GT * tj + (l & 15);
+  if (gi < n && gj < n) atomicAdd(&G[(size_t)gi * n + gj], sacc);
 }
 
 // column sums (only when centring is requested): one block row per column, grid-stride over rows
@@ -95,14 +162,19 @@ __global__ void k_gram_finish(double *__restrict__ G, const double *__restrict__
 
 // Round-robin parallel Jacobi on the symmetric n x n matrix A (global memory), eigenvectors in V.
 // np = n rounded up to even (a phantom index np-1 == n is skipped).
-__global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ A, double *__restrict__ V, int n, int max_sweeps,
+template <bool IN_LDS>  // IN_LDS: both n x n matrices live in LDS (n <= 64): latency ~100 ns instead of ~1.5 us
+__global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ Ag, double *__restrict__ Vg, int n, int max_sweeps,
                                                  double tol, int *__restrict__ sweeps_done) {
-  extern __shared__ double sm[];  // cs[np/2][2], pairs as ints after
+  extern __shared__ double sm[];  // cs[np/2][2], pairs as ints, then (IN_LDS) A and V
   const int np = (n + 1) & ~1, half = np / 2;
   double *rc = sm, *rs = sm + half;
   int *pp = reinterpret_cast<int *>(sm + 2 * half), *qq = pp + half;
+  double *A = IN_LDS ? sm + 3 * half + 2 : Ag;
+  double *V = IN_LDS ? A + (size_t)n * n : Vg;
   __shared__ double s_off;
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (IN_LDS)
+    for (int q = tid; q < n * n; q += nt) A[q] = Ag[q];
   for (int q = tid; q < n * n; q += nt) V[q] = (q / n == q % n) ? 1.0 : 0.0;
   __syncthreads();
   int sweep = 0;
@@ -158,28 +230,73 @@ __global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ A, double 
     __syncthreads();
   }
   if (tid == 0) *sweeps_done = sweep;
+  if (IN_LDS) {
+    __syncthreads();
+    for (int q = tid; q < n * n; q += nt) { Ag[q] = A[q]; Vg[q] = V[q]; }
+  }
 }
 
-// S[i][row] = sum_c Mr[c][i] (Wt[row][c] - mu[c])   (thread per row; M in LDS)
+// S[i][row] = sum_c Mr[c][i] (Wt[row][c] - mu[c]).  A wave takes 64 consecutive rows: the 64 x n
+// tile is contiguous in memory, so it is loaded with fully coalesced accesses into a padded LDS
+// tile (odd stride -> conflict-free column reads), then each lane reduces its own row.
+constexpr int PC = 64;  // columns per LDS chunk
 template <typename T>
 __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long long n_rows, int n, int r,
                                                  const double *__restrict__ Mr, const double *__restrict__ mu,
                                                  T *__restrict__ S) {
-  extern __shared__ double sm[];  // Mr [n][r], mu [n]
-  double *sM = sm, *smu = sm + (size_t)n * r;
-  for (int q = threadIdx.x; q < n * r; q += blockDim.x) sM[q] = Mr[q];
+  extern __shared__ double sm[];  // Mr [n][4] (zero padded), mu [n], then per-wave tiles of T
+  double *sM = sm, *smu = sm + 4 * (size_t)n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = min(n, PC), ldt = nc | 1;  // odd stride
+  T *tile = reinterpret_cast<T *>(smu + n) + (size_t)wave * 64 * ldt;
+  for (int q = threadIdx.x; q < 4 * n; q += blockDim.x) sM[q] = ((q & 3) < r) ? Mr[(size_t)(q >> 2) * r + (q & 3)] : 0.0;
   for (int q = threadIdx.x; q < n; q += blockDim.x) smu[q] = mu ? mu[q] : 0.0;
   __syncthreads();
-  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows;
-       row += (long long)gridDim.x * blockDim.x) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long base = (long long)blockIdx.x * 256 + 64 * wave; base < n_rows; base += stride) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
     double acc[4] = {0, 0, 0, 0};
-    const T *w = Wt + row * n;
-    for (int c = 0; c < n; ++c) {
-      const double x = (double)w[c] - smu[c];
-      for (int i = 0; i < 4; ++i)
-        if (i < r) acc[i] += x * sM[c * r + i];
+    for (int c0 = 0; c0 < n; c0 += PC) {
+      const int w = min(PC, n - c0);
+      if (w == n) {  // whole rows: the tile is one contiguous block of rows_here * n elements
+        const T *src = Wt + base * n;
+        if (sizeof(T) == 4 && (n & 3) == 0) {  // 16 B per lane; a float4 never straddles a row
+          const int n4 = n >> 2, total4 = rows_here * n4;
+          int rr = lane / n4, cc = lane - rr * n4;
+          const int sr = 64 / n4, sc = 64 - sr * n4;
+          const float4 *src4 = reinterpret_cast<const float4 *>(src);
+          for (int q = lane; q < total4; q += 64) {
+            const float4 v = src4[q];
+            T *d = tile + rr * ldt + 4 * cc;
+            d[0] = (T)v.x; d[1] = (T)v.y; d[2] = (T)v.z; d[3] = (T)v.w;
+            cc += sc; rr += sr;
+            if (cc >= n4) { cc -= n4; ++rr; }
+          }
+        } else {
+          int rr = lane / n, cc = lane - rr * n;
+          const int sr = 64 / n, sc = 64 - sr * n;
+          for (int q = lane; q < rows_here * n; q += 64) {
+            tile[rr * ldt + cc] = src[q];
+            cc += sc; rr += sr;
+            if (cc >= n) { cc -= n; ++rr; }
+          }
+        }
+      } else {
+        for (int q = lane; q < rows_here * w; q += 64) tile[(q / w) * ldt + (q % w)] = Wt[(base + q / w) * n + c0 + (q % w)];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < rows_here) {
+        const T *tr = tile + lane * ldt;
+        for (int c = 0; c < w; ++c) {
+          const double x = (double)tr[c] - smu[c0 + c];
+          const double *mc = sM + 4 * (size_t)(c0 + c);
+          acc[0] += x * mc[0]; acc[1] += x * mc[1]; acc[2] += x * mc[2]; acc[3] += x * mc[3];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    for (int i = 0; i < r; ++i) S[(size_t)i * n_rows + row] = (T)acc[i];
+    if (lane < rows_here)
+      for (int i = 0; i < r; ++i) S[(size_t)i * n_rows + base + lane] = (T)acc[i];
   }
 }
 
@@ -189,13 +306,13 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   hipStream_t st = nullptr;
   MVBA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   T *dW = nullptr, *dS = nullptr;
-  double *dG = nullptr, *dV = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr;
+  double *dG = nullptr, *dV = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr;
   int *dsw = nullptr;
   hipEvent_t ev[6];
   for (auto &e : ev) hipEventCreate(&e);
   int rc = MVBA_OK;
   auto cleanup = [&]() {
-    for (void *p : {(void *)dW, (void *)dS, (void *)dG, (void *)dV, (void *)dsum, (void *)dMr, (void *)dmu, (void *)dsw})
+    for (void *p : {(void *)dW, (void *)dS, (void *)dG, (void *)dV, (void *)dsum, (void *)dMr, (void *)dmu, (void *)dsw, (void *)dpart})
       if (p) hipFree(p);
     for (auto &e : ev) hipEventDestroy(e);
     hipStreamDestroy(st);
@@ -210,14 +327,23 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   SVD_HIP(hipMalloc((void **)&dMr, sizeof(double) * (size_t)n * n_rank));
   SVD_HIP(hipMalloc((void **)&dmu, sizeof(double) * n));
   SVD_HIP(hipMalloc((void **)&dsw, sizeof(int)));
+  const int n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
+  const bool fused = n_tiles <= 2;
+  const int chunks = (int)std::max<long long>(1, std::min<long long>((n_rows + 4 * ROWS_PER_STEP - 1) / (4 * ROWS_PER_STEP),
+                                                                    fused ? 2048 : std::max(8, 4096 / n_pairs)));
+  SVD_HIP(hipMalloc((void **)&dpart, sizeof(double) * (size_t)chunks * n_pairs * 256));
   hipEventRecord(ev[0], st);
   SVD_HIP(hipMemcpyAsync(dW, Wt, sizeof(T) * (size_t)n_rows * n, hipMemcpyHostToDevice, st));
   hipEventRecord(ev[1], st);
   SVD_HIP(hipMemsetAsync(dG, 0, sizeof(double) * nn, st));
   SVD_HIP(hipMemsetAsync(dsum, 0, sizeof(double) * n, st));
-  const int n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
-  const int chunks = (int)std::max<long long>(1, std::min<long long>((n_rows + GR - 1) / GR, std::max(1, 4096 / n_pairs)));
-  hipLaunchKernelGGL(k_gram<T>, dim3(n_pairs, chunks), dim3(256), 0, st, dW, n_rows, n, n_tiles, dG);
+  if (n_tiles == 1)
+    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), 0, st, dW, n_rows, n, dpart);
+  else if (n_tiles == 2)
+    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), 0, st, dW, n_rows, n, dpart);
+  else
+    hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, st, dW, n_rows, n, n_tiles, n_pairs, dpart);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, std::min(chunks, 32)), dim3(256), 0, st, dpart, chunks, n, n_tiles, n_pairs, dG);
   if (center) {
     const int cy = (int)std::max<long long>(1, std::min<long long>(256, n_rows / 4096));
     hipLaunchKernelGGL(k_colsum<T>, dim3(n, cy), dim3(256), 0, st, dW, n_rows, n, dsum);
@@ -225,8 +351,11 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, st, dG, dsum, n, n_rows, center);
   hipEventRecord(ev[2], st);
   const int np = (n + 1) & ~1;
-  const size_t jl = sizeof(double) * np + sizeof(int) * np;
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(1024), jl, st, dG, dV, n, 60, 1e-15, dsw);
+  const size_t jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
+  if (n <= 64)
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, st, dG, dV, n, 60, 1e-15, dsw);
+  else
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, st, dG, dV, n, 60, 1e-15, dsw);
   hipEventRecord(ev[3], st);
   // eigenvalues -> host, sort, build the rank-r basis with a deterministic sign
   std::vector<double> hG(nn), hV(nn), hsum(n);
@@ -258,8 +387,10 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   SVD_HIP(hipMemcpyAsync(dmu, mu.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
   hipEventRecord(ev[4], st);
   const int pgrid = (int)std::max<long long>(1, std::min<long long>(4096, (n_rows + 255) / 256));
-  hipLaunchKernelGGL(k_project<T>, dim3(pgrid), dim3(256), sizeof(double) * ((size_t)n * n_rank + n), st, dW, n_rows, n,
-                     n_rank, dMr, center ? dmu : nullptr, dS);
+  const int ldt = std::min(n, PC) | 1;
+  const size_t plds = sizeof(double) * (5 * (size_t)n) + sizeof(T) * 4 * 64 * (size_t)ldt + 16;
+  hipLaunchKernelGGL(k_project<T>, dim3(pgrid), dim3(256), plds, st, dW, n_rows, n, n_rank, dMr,
+                     center ? dmu : nullptr, dS);
   hipEventRecord(ev[5], st);
   SVD_HIP(hipMemcpyAsync(S, dS, sizeof(T) * (size_t)n_rows * n_rank, hipMemcpyDeviceToHost, st));
   SVD_HIP(hipStreamSynchronize(st));
@@ -289,6 +420,7 @@ extern "C" int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, i
     return fail(MVBA_ERR_BADARG, "need n_rows >= 1, 1 <= n_rank <= min(4, n_cols), n_cols <= 2048");
   if (dtype != 0 && dtype != 1) return fail(MVBA_ERR_BADARG, "dtype must be 0 (float32) or 1 (float64)");
   if (device >= 0) MVBA_HIP(hipSetDevice(device));
+  MVBA_HIP(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   MVBA_HIP(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   MVBA_HIP(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   if (dtype == 0)
