@@ -77,7 +77,7 @@ __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
 // Algorithmic traffic: 24 B in + 128 B out per observation + (24 in + 72 out) B per point.
 constexpr int REC = 8;  // double2 slots per observation record (128 B)
 
-__global__ __launch_bounds__(256) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
+__global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
                                                    const double *__restrict__ X,
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
@@ -416,7 +416,7 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // entries of L are broadcast with v_readlane (SGPR operands): no LDS, no barriers, every
 // index static.  Every wave re-factors the tile (cheap) so the panel needs one launch.
 __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int ld, int D, int j0, int nb,
-                                                   int *__restrict__ flag) {
+                                                   double *__restrict__ dinv, int *__restrict__ flag) {
   const int lane = threadIdx.x;
   const int r = lane & 31;
   double a[NB];
@@ -432,20 +432,25 @@ __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int l
   for (int k = 0; k < NB; ++k) {
     const double piv = readlane_d(a[k], k);
     bad |= !(piv > 0.0);
-    const double lkk = sqrt(piv);
-    rinv[k] = 1.0 / lkk;
-    a[k] = (r == k) ? lkk : a[k] * rinv[k];
+    // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
+    // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
+    double y = __builtin_amdgcn_rsq(piv);
+    y = y * (1.5 - 0.5 * piv * y * y);
+    y = y * (1.5 - 0.5 * piv * y * y);
+    rinv[k] = y;
+    a[k] = (r == k) ? piv * y : a[k] * y;
+    // entries above the diagonal (c > r) hold garbage that is never read: no predicate needed
 #pragma unroll
-    for (int c = k + 1; c < NB; ++c) {
-      const double lck = readlane_d(a[k], c);
-      if (r >= c) a[c] -= a[k] * lck;
-    }
+    for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
   }
   if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
   if (blockIdx.x == 0 && lane < NB && r < nb) {
 #pragma unroll
     for (int c = 0; c < NB; ++c)
       if (c <= r && c < nb) M[(size_t)(j0 + r) * ld + j0 + c] = a[c];
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c == r) dinv[j0 + r] = rinv[c];  // reciprocal diagonal for the back-substitution
   }
   // rows below the tile (row D = rhs included): X L^T = P, one row per lane
   const int row = j0 + nb + blockIdx.x * 64 + lane;
@@ -509,12 +514,16 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 }
 
 // L^T x = y (y = row D), single workgroup; scatter x into the full 9m vector (zeros at the gauge slots).
+// Per 32-column block: wave 0 solves the diagonal tile from LDS with reciprocal diagonals (no
+// divides on the serial path) while every thread already has the operands of the following
+// update y[c] -= sum_r L[jb+r][c] x[jb+r] in flight.
 __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restrict__ M, int ld, int D, int m,
-                                                         int gauge_axis, double *__restrict__ dxi_full) {
-  extern __shared__ double y[];  // D doubles
+                                                         int gauge_axis, const double *__restrict__ dinv,
+                                                         double *__restrict__ dxi_full) {
+  extern __shared__ double y[];  // D + NB doubles (zero tail: the last block may be partial)
   __shared__ double T[NB][NB + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < D; i += blockDim.x) y[i] = M[(size_t)D * ld + i];
+  for (int i = tid; i < D + NB; i += blockDim.x) y[i] = (i < D) ? M[(size_t)D * ld + i] : 0.0;
   for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
   __syncthreads();
   const int nblk = (D + NB - 1) / NB;
@@ -522,24 +531,35 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restric
     const int jb = bi * NB, nb = min(NB, D - jb);
     {
       const int r = tid / NB, c = tid % NB;  // 1024 threads = one tile
-      T[r][c] = (r < nb && c <= r) ? M[(size_t)(jb + r) * ld + jb + c] : (r == c ? 1.0 : 0.0);
+      T[r][c] = (r < nb && c < r) ? M[(size_t)(jb + r) * ld + jb + c] : 0.0;
     }
+    // operands of this block's update, one column c per thread (rows jb..jb+nb-1 of L)
+    double lcol[NB];
+    const int cc = tid;  // D <= 1024 * k handled by the strided loop below for cc >= 1024
+#pragma unroll
+    for (int r = 0; r < NB; ++r) lcol[r] = (cc < jb && r < nb) ? M[(size_t)(jb + r) * ld + cc] : 0.0;
     __syncthreads();
     if (wave == 0) {
       double xr = (lane < nb) ? y[jb + lane] : 0.0;
+      const double di = (lane < nb) ? dinv[jb + lane] : 0.0;
       for (int k = nb - 1; k >= 0; --k) {
-        const double xk = __shfl(xr, k, 64) / T[k][k];
+        const double xk = __shfl(xr * di, k, 64);
         if (lane == k) xr = xk;
         if (lane < k) xr -= T[k][lane] * xk;
       }
       if (lane < nb) y[jb + lane] = xr;
     }
     __syncthreads();
-    for (int cc = tid; cc < jb; cc += blockDim.x) {
+    if (cc < jb) {
       double sacc = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < nb; ++r) sacc += M[(size_t)(jb + r) * ld + cc] * y[jb + r];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) sacc += lcol[r] * y[jb + r];  // y[jb + r] = 0-weighted beyond nb via lcol = 0
       y[cc] -= sacc;
+    }
+    for (int c2 = tid + blockDim.x; c2 < jb; c2 += blockDim.x) {  // D > 1024
+      double sacc = 0.0;
+      for (int r = 0; r < nb; ++r) sacc += M[(size_t)(jb + r) * ld + c2] * y[jb + r];
+      y[c2] -= sacc;
     }
     __syncthreads();
   }
@@ -668,7 +688,7 @@ struct mvba_handle {
   double2 *d_xy = nullptr;
   int4 *d_csc = nullptr;
   long long *d_chunk_ptr = nullptr;
-  int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768;
+  int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768, k1_threads = 512;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
@@ -677,7 +697,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -846,6 +866,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   h->nchunks = (int)std::max<long long>(1, std::min<long long>((3072 + m - 1) / m, avg_len / 256));
   // tuning overrides (experiments only)
   if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(768, atoi(ev) / 64 * 64));
+  if (const char *ev = getenv("MVBA_K1_THREADS")) h->k1_threads = std::max(64, std::min(512, atoi(ev) / 64 * 64));
   if (const char *ev = getenv("MVBA_SCHUR_CHUNKS")) h->nchunks = std::max(1, atoi(ev));
   const size_t lds_cap = 150 * 1024;
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
@@ -879,6 +900,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, n9 * n9 + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
+  TRY(dmalloc(&h->d_dinv, h->D + NB));
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
   TRY(dmalloc(&h->d_partials, h->n_partials));
@@ -902,9 +924,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
-                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double))));
+                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->D * sizeof(double))));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((h->D + NB) * sizeof(double))));
 #undef TRY
 #undef TRYH
   *out = h;
@@ -917,7 +939,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -979,9 +1001,10 @@ int mvba_linearize(mvba_handle *h) {
   MVBA_HIP(hipMemsetAsync(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(h->N, 1), h->stream));
   if (h->nobs) {
     Timed t(h, MVBA_K_RESID_JAC);  // K1 with K2 (per-point blocks) fused in
-    const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + 4 * 64 * 2 * REC) * sizeof(double);
-    const int grid = (int)std::min<long long>(2048, (h->nobs + 255) / 256);
-    hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(256), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
+    const int kt = h->k1_threads;  // 8 waves share one camera table: 2 blocks = 16 waves per CU
+    const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + (kt / 64) * 64 * 2 * REC) * sizeof(double);
+    const int grid = (int)std::min<long long>(2048 * 256 / kt, (h->nobs + kt - 1) / kt);
+    hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(kt), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
                        h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_rec, h->d_PL);
   }
   MVBA_HIP(hipGetLastError());
@@ -1025,14 +1048,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const int nb = std::min(NB, D - j0);
       const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
       hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(64), 0, h->stream, h->d_Ared, ld, D, j0, nb,
-                         h->d_flag);
+                         h->d_dinv, h->d_flag);
       if (j0 + nb < D) {
         const int nt = (rows_below + 63) / 64;
         hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, j0);
       }
     }
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), D * sizeof(double), h->stream, h->d_Ared, ld, D, m,
-                       h->gauge_axis, h->d_dxi);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), (D + NB) * sizeof(double), h->stream, h->d_Ared, ld, D, m,
+                       h->gauge_axis, h->d_dinv, h->d_dxi);
   }
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
