@@ -283,12 +283,15 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     const char *ql = line(ol);
     double2 x0 = *reinterpret_cast<const double2 *>(ql), x1 = *reinterpret_cast<const double2 *>(ql + 16),
             x2 = *reinterpret_cast<const double2 *>(ql + 32), cs = *reinterpret_cast<const double2 *>(ql + sel16);
+    // the diagonal item always lands on the same addresses for a given lane (slot 0, l == k):
+    // its rhs and Marquardt-damping terms accumulate in registers and are flushed once per wave
+    double bacc = 0.0, dacc = 0.0;
     while (true) {
       // ---------------- compute pass n
       const bool valid = act && slot < 7 && l >= l_lo && l < l_hi;
       double *dst = strip + (9 * (l - l_lo) + j) * 9;
       const bool diag = valid && (base + slot == 0);
-      double val[9], bval = 0.0, dval = 0.0;
+      double val[9];
       {
         const double cjx = alpha * cs.x + beta_x, cjy = alpha * cs.y + beta_y;  // 4 * Jc_l[:, j]
         const double g0 = x0.x * cjx + x0.y * cjy;  // 2 * F_al[:, j]
@@ -306,12 +309,12 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           const double d0 = 0.5 * cjx, d1 = 0.5 * cjy;  // 2 * Jc_k[:, j]
           t0 -= d0;
           t1 -= d1;
-          dval = c * 0.125 * (cjx * cjx + cjy * cjy);  // c * 2 |Jc_k[:, j]|^2
+          dacc += c * 0.125 * (cjx * cjx + cjy * cjy);  // c * 2 |Jc_k[:, j]|^2
           const double *pv = PBg + 10 * (size_t)cur.y + 6;
           const double2 ke = *reinterpret_cast<const double2 *>(line(cur.x) + 112);
           const double w0 = kx00 * pv[0] + kx01 * pv[1] + kx02 * pv[2] - ke.x;
           const double w1 = kx10 * pv[0] + kx11 * pv[1] + kx12 * pv[2] - ke.y;
-          bval = d0 * w0 + d1 * w1;
+          bacc += d0 * w0 + d1 * w1;
         }
         // -(Jc_k[:, i] . t) for i = f, u, v, t(3), omega(3)   (t columns of Jc are -Jx)
         val[0] = -(kf0 * t0 + kf1 * t1);
@@ -361,12 +364,12 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       if (valid) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) atomicAdd(dst + i, val[i]);
-        if (diag) {
-          atomicAdd(dst + j, dval);  // (1+c) damping of G_k's diagonal (ref :123-125)
-          atomicAdd(&sb[j], bval);
-        }
       }
       if (done) break;
+    }
+    if (seg == 0 && lane < 9) {
+      atomicAdd(strip + lane * 9 + lane, dacc);  // (1+c) damping of G_k's diagonal (ref :123-125)
+      atomicAdd(&sb[lane], bacc);
     }
   }
   __syncthreads();
