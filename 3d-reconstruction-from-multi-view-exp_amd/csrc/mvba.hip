@@ -598,8 +598,12 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 }
 
 // ------------------------------------------------------------------ K5+K6
-// One thread per point: dX_a = -E^-1 (sum_k F_ak dxi_k + dP_a), X' = X + dX, then the
-// point's residuals at the trial cameras.  partials[block] = block cost (fixed tree).
+// Eight lanes per point, one observation per lane (a point's records are consecutive 128-byte
+// lines, so the 8 lanes of a group stream 1 KiB contiguous): every lane forms
+// y_o = 2 Jx^T (Jc dxi_k) for its observations, the group adds them up (3 values, 3 butterfly
+// steps per point), dX_a = -E^-1 (sum_o y_o + dP_a), X' = X + dX, then the point's residuals at
+// the trial cameras with the same lane <-> observation mapping.  Grid-stride over groups of 32
+// points; partials[block] = block cost (fixed tree, fixed grid -> deterministic).
 __global__ __launch_bounds__(256) void k_backsub_cost(
     long long npts, int m, const long long *__restrict__ pt_ptr, const int *__restrict__ cam_idx,
     const double2 *__restrict__ xy, const double2 *__restrict__ rec,
@@ -612,33 +616,41 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
   for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
   load_cams_to_lds(cam15_trial, m, f0, s_cam);
   __syncthreads();
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const double cu = 1.0 / f0;
   double cost = 0.0;
-  if (a < npts) {
+  for (long long a = (long long)blockIdx.x * 32 + grp; a < npts; a += (long long)gridDim.x * 32) {
     const long long o0 = pt_ptr[a], o1 = pt_ptr[a + 1];
-    double acc0 = 0, acc1 = 0, acc2 = 0;
-    const double cu = 1.0 / f0;
-    for (long long o = o0; o < o1; ++o) {
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    for (long long o = o0 + s; o < o1; o += 8) {
       const double *dk = s_dxi + 9 * cam_idx[o];
       const double2 *q = rec + o * REC;
       const double2 x0 = q[0], x1 = q[1], x2 = q[2], jf = q[3], w0 = q[4], w1 = q[5], w2 = q[6];
-      // s = J_C dxi_k with the implied columns: (u,v) -> 1/f0, t -> -J_X
+      // Jc dxi_k with the implied columns: (u,v) -> 1/f0, t -> -J_X
       const double s0 = jf.x * dk[0] + cu * dk[1] - (x0.x * dk[3] + x1.x * dk[4] + x2.x * dk[5]) +
                         (w0.x * dk[6] + w1.x * dk[7] + w2.x * dk[8]);
       const double s1 = jf.y * dk[0] + cu * dk[2] - (x0.y * dk[3] + x1.y * dk[4] + x2.y * dk[5]) +
                         (w0.y * dk[6] + w1.y * dk[7] + w2.y * dk[8]);
-      acc0 += 2.0 * (x0.x * s0 + x0.y * s1);
-      acc1 += 2.0 * (x1.x * s0 + x1.y * s1);
-      acc2 += 2.0 * (x2.x * s0 + x2.y * s1);
+      y0 += 2.0 * (x0.x * s0 + x0.y * s1);
+      y1 += 2.0 * (x1.x * s0 + x1.y * s1);
+      y2 += 2.0 * (x2.x * s0 + x2.y * s1);
+    }
+#pragma unroll
+    for (int msk = 1; msk < 8; msk <<= 1) {  // fixed butterfly: every lane ends with the group sum
+      y0 += __shfl_xor(y0, msk, 8);
+      y1 += __shfl_xor(y1, msk, 8);
+      y2 += __shfl_xor(y2, msk, 8);
     }
     const double *pb = PB + 10 * a;
-    const double d0 = -(pb[0] * acc0 + pb[1] * acc1 + pb[2] * acc2) - pb[6];
-    const double d1 = -(pb[1] * acc0 + pb[3] * acc1 + pb[4] * acc2) - pb[7];
-    const double d2 = -(pb[2] * acc0 + pb[4] * acc1 + pb[5] * acc2) - pb[8];
+    const double d0 = -(pb[0] * y0 + pb[1] * y1 + pb[2] * y2) - pb[6];
+    const double d1 = -(pb[1] * y0 + pb[3] * y1 + pb[4] * y2) - pb[7];
+    const double d2 = -(pb[2] * y0 + pb[4] * y1 + pb[5] * y2) - pb[8];
     const double X0 = X[3 * a] + d0, X1 = X[3 * a + 1] + d1, X2 = X[3 * a + 2] + d2;
-    dX[3 * a] = d0; dX[3 * a + 1] = d1; dX[3 * a + 2] = d2;
-    Xt[3 * a] = X0; Xt[3 * a + 1] = X1; Xt[3 * a + 2] = X2;
-    for (long long o = o0; o < o1; ++o) {
+    if (s == 0) {
+      dX[3 * a] = d0; dX[3 * a + 1] = d1; dX[3 * a + 2] = d2;
+      Xt[3 * a] = X0; Xt[3 * a + 1] = X1; Xt[3 * a + 2] = X2;
+    }
+    for (long long o = o0 + s; o < o1; o += 8) {
       const double2 z = xy[o];
       cost += obs_cost(X0, X1, X2, s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
     }
@@ -885,7 +897,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   }
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
   const int pt_blocks = (int)((N + 255) / 256);
-  h->n_partials = std::max(h->cost_grid, std::max(pt_blocks, 1));
+  h->n_partials = std::max(h->cost_grid, std::max(std::max(pt_blocks, 1), 4096));
 
 #define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -1066,7 +1078,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_BACKSUB_COST);
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
-    const int nblk = (int)((h->N + 255) / 256);
+    const int nblk = (int)std::min<long long>(4096, (h->N + 31) / 32);
     if (nblk) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
       hipLaunchKernelGGL(k_backsub_cost, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam,
