@@ -61,6 +61,13 @@ __device__ __forceinline__ void load_cams_to_lds(const double *__restrict__ cam1
   for (int k = threadIdx.x; k < m; k += blockDim.x) expand_cam(cam15 + (size_t)k * CAM_IN, f0, s_cam + k * CAM_LDS);
 }
 
+// Reduced system storage: the upper block triangle of A packed strip by strip -- strip k is a
+// row-major 9 x 9(m-k) block (cameras l >= k) at offset 81 (k m - k (k-1) / 2) -- followed by b
+// (9m).  81 m (m+1) / 2 + 9m doubles: half of the dense 9m x 9m, and what the all-reduce ships.
+__host__ __device__ __forceinline__ size_t strip_offset(int k, int m) {
+  return 81 * ((size_t)k * m - (size_t)k * (k - 1) / 2);
+}
+
 __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
   // i-th kept parameter -> global parameter index; removed = {3..8, 12+axis} (ref :62-72)
   if (i < 3) return i;
@@ -373,11 +380,12 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     }
   }
   __syncthreads();
-  const size_t ld = 9 * (size_t)m;
+  double *Ak = Afull + strip_offset(k, m) + 9 * (size_t)(l_lo - k);  // packed strip k, first column of this segment
+  const int Wk = 9 * (m - k);
   for (int q = threadIdx.x; q < 9 * W; q += blockDim.x) {
     const int row = q / W, col = q - row * W;  // coalesced over the columns of A
     const double val = strip[col * 9 + row];
-    if (val != 0.0) atomicAdd(&Afull[(9 * (size_t)k + row) * ld + 9 * (size_t)l_lo + col], val);
+    if (val != 0.0) atomicAdd(&Ak[(size_t)row * Wk + col], val);
   }
   if (seg == 0 && threadIdx.x < 9) atomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
 }
@@ -405,9 +413,10 @@ __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__
   }
   if (j > i) return;
   const int gi = keep_index(i, gauge_axis);
-  const size_t l9 = 9 * (size_t)m;
-  // only the upper block triangle of Afull is populated: read (min,max)
-  M[(size_t)i * ld + j] = Afull[(size_t)min(gi, gj) * l9 + max(gi, gj)];
+  // only the upper block triangle is stored: read (min,max) from the packed strips
+  const int r = min(gi, gj), c = max(gi, gj);
+  const int k = r / 9, l = c / 9;
+  M[(size_t)i * ld + j] = Afull[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
 }
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -913,7 +922,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_PL, 9 * N));
   TRY(dmalloc(&h->d_PB, 10 * N));
   const size_t n9 = 9 * (size_t)m;
-  TRY(dmalloc(&h->d_Ab, n9 * n9 + n9));
+  TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
   TRY(dmalloc(&h->d_dinv, h->D + NB));
   TRY(dmalloc(&h->d_dxi, n9));
@@ -1034,8 +1043,9 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   MVBA_HIP(hipSetDevice(h->device));
   const int m = h->m, D = h->D;
   const size_t n9 = 9 * (size_t)m;
-  double *d_A = h->d_Ab, *d_b = h->d_Ab + n9 * n9;
-  MVBA_HIP(hipMemsetAsync(h->d_Ab, 0, sizeof(double) * (n9 * n9 + n9), h->stream));
+  const size_t nA = strip_offset(m, m);  // packed upper block triangle
+  double *d_A = h->d_Ab, *d_b = h->d_Ab + nA;
+  MVBA_HIP(hipMemsetAsync(h->d_Ab, 0, sizeof(double) * (nA + n9), h->stream));
   if (h->N) {
     Timed t(h, MVBA_K_POINT_INV);
     hipLaunchKernelGGL(k_point_inv, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, c, h->d_PL,
@@ -1051,7 +1061,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   MVBA_HIP(hipGetLastError());
   if (h->comm) {
     Timed t(h, MVBA_K_ALLREDUCE);
-    ncclResult_t r = ncclAllReduce(h->d_Ab, h->d_Ab, n9 * n9 + n9, ncclDouble, ncclSum, h->comm, h->stream);
+    ncclResult_t r = ncclAllReduce(h->d_Ab, h->d_Ab, nA + n9, ncclDouble, ncclSum, h->comm, h->stream);
     if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
   }
   {
@@ -1208,13 +1218,20 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
       if (which == MVBA_BUF_E) for (int i = 0; i < 6; ++i) out[6 * a + i] = pl[9 * a + i];
       else for (int i = 0; i < 3; ++i) out[3 * a + i] = pl[9 * a + 6 + i];
     }
-  } else if (which == MVBA_BUF_A_FULL) {
-    MVBA_HIP(d2h(h->d_Ab, sizeof(double) * cnt));
-    for (size_t r = 0; r < n9; ++r)  // mirror the populated upper block triangle
-      for (size_t cc = r + 1; cc < n9; ++cc)
-        if (r / 9 != cc / 9) out[cc * n9 + r] = out[r * n9 + cc];
+  } else if (which == MVBA_BUF_A_FULL) {  // expand the packed strips to the dense symmetric matrix
+    const int m = h->m;
+    std::vector<double> pk(strip_offset(m, m));
+    MVBA_HIP(hipMemcpy(pk.data(), h->d_Ab, sizeof(double) * pk.size(), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < n9; ++r)
+      for (size_t cc = 0; cc < n9; ++cc) {
+        const size_t lo = std::min(r, cc), hi = std::max(r, cc);
+        const int k = (int)(lo / 9), l = (int)(hi / 9);
+        // inside a diagonal block both halves are stored: keep the entry as computed
+        const size_t rr = (k == l) ? r : lo, c2 = (k == l) ? cc : hi;
+        out[r * n9 + cc] = pk[strip_offset(k, m) + (rr - 9 * k) * (size_t)(9 * (m - k)) + (c2 - 9 * k)];
+      }
   } else if (which == MVBA_BUF_B_FULL) {
-    MVBA_HIP(d2h(h->d_Ab + n9 * n9, sizeof(double) * cnt));
+    MVBA_HIP(d2h(h->d_Ab + strip_offset(h->m, h->m), sizeof(double) * cnt));
   } else if (which == MVBA_BUF_DXI) {
     MVBA_HIP(d2h(h->d_dxi, sizeof(double) * cnt));
   } else if (which == MVBA_BUF_DX) {

@@ -249,3 +249,28 @@ def test_virtual_point_shards_sum_to_the_full_reduced_system():
     # two runs differ by the order of the Schur atomics: eps x cond(A) on the solution
     np.testing.assert_allclose(withc.debug_read("dxi"), full.debug_read("dxi"), rtol=0, atol=1e-9 * np.abs(full.debug_read("dxi")).max())
     assert withc.cost() == pytest.approx(full.cost(), rel=1e-13)
+
+
+@pytest.mark.parametrize("n,m,p", [(40, 2, 1.0), (900, 300, 0.06)])
+def test_extreme_camera_counts_vs_oracle(n, m, p):
+    """m = 2 (smallest legal gauge: D = 11) and m = 300 (the LDS strip of one camera no longer
+    fits and is cut into column segments, the path BASELINE config 4 with m = 500 takes)."""
+    sc = make_scene(n, m, vis_p=p)
+    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                          sc.init_R, sc.init_t, axis=sc.axis)
+    g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
+    eng = ba._engine
+    assert eng.cost() == pytest.approx(g.cost(), rel=1e-12)
+    eng.linearize(); g.linearize()
+    c = 1e-4 if m == 2 else 1e-2
+    E1 = eng.try_step(c)
+    A, b = g.reduced_system(c)
+    E1o = g.try_step(c)
+    m9 = 9 * m
+    np.testing.assert_allclose(eng.debug_read("A_full").reshape(m9, m9), A, rtol=0, atol=1e-11 * np.abs(A).max())
+    np.testing.assert_allclose(eng.debug_read("b_full"), b, rtol=0, atol=1e-9 * np.abs(b).max())
+    dxi = np.zeros(m9); dxi[g.keep] = g.dxi_red
+    np.testing.assert_allclose(eng.debug_read("dxi"), dxi, rtol=0, atol=1e-7 * np.abs(dxi).max())
+    assert E1 == pytest.approx(E1o, rel=1e-7)
