@@ -578,6 +578,80 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restric
   for (int i = tid; i < D; i += blockDim.x) dxi_full[keep_index(i, gauge_axis)] = y[i];
 }
 
+// ---- fallback: LU with partial pivoting (what np.linalg.solve / LAPACK gesv does, ref :146) ----
+// Only reached when the Cholesky meets a non-positive pivot (reduced system not positive definite,
+// e.g. a negative damping factor).  Slow (one workgroup, D sequential steps) but rare.
+__global__ void k_compact_full(int D, int m, int gauge_axis, const double *__restrict__ Apk,
+                               const double *__restrict__ bfull, double *__restrict__ F, double *__restrict__ rhs) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= D) return;
+  const int gi = keep_index(i, gauge_axis), gj = keep_index(j, gauge_axis);
+  const int r = min(gi, gj), c = max(gi, gj);
+  const int k = r / 9;
+  F[(size_t)i * D + j] = Apk[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
+  if (j == 0) rhs[i] = bfull[gi];
+}
+
+__global__ __launch_bounds__(1024) void k_lu_solve(double *__restrict__ F, double *__restrict__ rhs, int D, int m,
+                                                   int gauge_axis, double *__restrict__ dxi_full, int *__restrict__ flag) {
+  __shared__ double s_val[1024];
+  __shared__ int s_idx[1024];
+  __shared__ int s_piv;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = 0; k < D; ++k) {
+    // pivot search in column k
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < D; i += nt) {
+      const double v = fabs(F[(size_t)i * D + k]);
+      if (v > best) { best = v; bi = i; }
+    }
+    s_val[tid] = best; s_idx[tid] = bi;
+    __syncthreads();
+    for (int off = nt >> 1; off > 0; off >>= 1) {
+      if (tid < off && (s_val[tid + off] > s_val[tid] || (s_val[tid + off] == s_val[tid] && s_idx[tid + off] < s_idx[tid]))) {
+        s_val[tid] = s_val[tid + off]; s_idx[tid] = s_idx[tid + off];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      s_piv = s_idx[0];
+      if (!(s_val[0] > 0.0)) atomicOr(flag, 4);  // exactly singular: LAPACK's info > 0 -> LinAlgError
+    }
+    __syncthreads();
+    const int p = s_piv;
+    if (p != k) {  // swap rows k and p (and the right-hand side)
+      for (int j = tid; j < D; j += nt) {
+        const double a = F[(size_t)k * D + j];
+        F[(size_t)k * D + j] = F[(size_t)p * D + j];
+        F[(size_t)p * D + j] = a;
+      }
+      if (tid == 0) { const double a = rhs[k]; rhs[k] = rhs[p]; rhs[p] = a; }
+    }
+    __syncthreads();
+    const double piv = F[(size_t)k * D + k];
+    for (int i = k + 1 + tid; i < D; i += nt) F[(size_t)i * D + k] /= piv;  // multipliers
+    __syncthreads();
+    const int rem = D - k - 1;
+    for (long long q = tid; q < (long long)rem * rem; q += nt) {  // rank-1 update of the trailing block
+      const int i = k + 1 + (int)(q / rem), j = k + 1 + (int)(q % rem);
+      F[(size_t)i * D + j] -= F[(size_t)i * D + k] * F[(size_t)k * D + j];
+    }
+    for (int i = k + 1 + tid; i < D; i += nt) rhs[i] -= F[(size_t)i * D + k] * rhs[k];  // forward substitution
+    __syncthreads();
+  }
+  for (int k = D - 1; k >= 0; --k) {  // back substitution with U
+    if (tid == 0) rhs[k] /= F[(size_t)k * D + k];
+    __syncthreads();
+    const double xk = rhs[k];
+    for (int i = tid; i < k; i += nt) rhs[i] -= F[(size_t)i * D + k] * xk;
+    __syncthreads();
+  }
+  for (int i = tid; i < 9 * m; i += nt) dxi_full[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < D; i += nt) dxi_full[keep_index(i, gauge_axis)] = rhs[i];
+}
+
 // ------------------------------------------------------------------ K6a: trial cameras (ref :263-281, utils.py:10-29)
 __global__ void k_update_cams(int m, const double *__restrict__ cam15, const double *__restrict__ dxi,
                               double *__restrict__ out15) {
@@ -721,7 +795,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_dxi = nullptr, *d_dX = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -963,7 +1037,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -1084,7 +1158,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   }
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
-  {
+  auto launch_tail = [&]() {  // K6a + K5/K6: trial cameras, back-substitution, trial cost
     Timed t(h, MVBA_K_BACKSUB_COST);
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
@@ -1096,15 +1170,38 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
                          h->d_X[trial], h->d_dX, h->d_partials);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost);
-  }
+  };
+  launch_tail();
   MVBA_HIP(hipGetLastError());
   h->stats.n_try_step++;
   int rc = global_cost(h, E_trial);
   if (rc) return rc;
+  if ((*h->h_flag & 2) && !(*h->h_flag & 1)) {
+    // The Cholesky met a non-positive pivot: the reduced system is not positive definite (e.g. a
+    // negative damping factor).  The reference's np.linalg.solve is LU with partial pivoting and
+    // does not care, so redo the solve that way (slow path, rare) and the tail of the step.
+    if (!h->d_lu) {
+      int rc_ = dmalloc(&h->d_lu, (size_t)D * D + D);
+      if (rc_) return rc_;
+    }
+    MVBA_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+    {
+      Timed t(h, MVBA_K_SOLVE);
+      hipLaunchKernelGGL(k_compact_full, dim3((D + 255) / 256, D), dim3(256), 0, h->stream, D, m, h->gauge_axis, d_A, d_b,
+                         h->d_lu, h->d_lu + (size_t)D * D);
+      hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), 0, h->stream, h->d_lu, h->d_lu + (size_t)D * D, D, m,
+                         h->gauge_axis, h->d_dxi, h->d_flag);
+    }
+    h->stats.n_lu_fallback++;
+    launch_tail();
+    MVBA_HIP(hipGetLastError());
+    rc = global_cost(h, E_trial);
+    if (rc) return rc;
+  }
   if (*h->h_flag) {
     const int fl = *h->h_flag;
     hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
-    return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system not positive definite)");
+    return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system)");
   }
   h->have_trial = true;
   return MVBA_OK;

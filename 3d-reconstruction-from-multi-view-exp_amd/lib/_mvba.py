@@ -32,7 +32,8 @@ class Problem(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ms", C.c_double * 16), ("launches", C.c_int64 * 16),
-                ("n_linearize", C.c_int64), ("n_try_step", C.c_int64), ("n_commit", C.c_int64)]
+                ("n_linearize", C.c_int64), ("n_try_step", C.c_int64), ("n_commit", C.c_int64),
+                ("n_lu_fallback", C.c_int64)]
 
 
 # every symbol include/mvba.h declares: (restype, argtypes)
@@ -177,7 +178,8 @@ class HipEngine:
         s = Stats()
         raise_for(self.lib.mvba_get_stats(self._h, C.byref(s)), self.lib)
         out = {k: {"ms": s.ms[i], "launches": s.launches[i]} for i, k in enumerate(KERNEL_IDS)}
-        out["counts"] = {"linearize": s.n_linearize, "try_step": s.n_try_step, "commit": s.n_commit}
+        out["counts"] = {"linearize": s.n_linearize, "try_step": s.n_try_step, "commit": s.n_commit,
+                         "lu_fallback": s.n_lu_fallback}
         return out
 
     def comm_init(self, id128: bytes, rank: int, n_ranks: int):

@@ -68,6 +68,7 @@ typedef struct mvba_stats {
   double ms[16];        /* accumulated device time per kernel id (hipEvents on the library's stream) */
   int64_t launches[16]; /* number of timed launches per kernel id                */
   int64_t n_linearize, n_try_step, n_commit;
+  int64_t n_lu_fallback; /* solves that left the Cholesky path for LU with partial pivoting */
 } mvba_stats;
 
 const char *mvba_version(void);

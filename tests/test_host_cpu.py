@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_mvba.Problem) == 64
-    assert ctypes.sizeof(_mvba.Stats) == 16 * 8 * 2 + 24
+    assert ctypes.sizeof(_mvba.Stats) == 16 * 8 * 2 + 32
 
 
 def test_host_obs_math_matches_oracle():
