@@ -208,7 +208,7 @@ def main():
                          "algorithmic_bytes_per_obs": 152, "avg_launch_ms": k1_ms},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # CPU baseline and SVD leg: rank 0 at N = 1 only
             eng.close()
             out["cpu_baseline"] = cpu_baseline(n_total, args.cams, args.vis, n_obs_total,
                                                min(args.cpu_sample_points, args.points))
