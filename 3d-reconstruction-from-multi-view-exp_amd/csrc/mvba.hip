@@ -95,9 +95,11 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
   double2 *stage = reinterpret_cast<double2 *>(smem + ((m * CAM_LDS + 1) & ~1)) + wave * (64 * REC);
-  // the same 8 KiB is reused for the per-point sums: contrib[9][64] doubles, then seg_start[65], pt[64]
+  // the same 8 KiB is reused for the per-point sums: contrib[9][CS] doubles (odd stride: the nine
+  // components of one observation sit in nine different banks), then seg_start[65], pt[64]
+  constexpr int CS = 65;
   double *contrib = reinterpret_cast<double *>(stage);
-  int *seg_start = reinterpret_cast<int *>(contrib + 9 * 64), *seg_pt = seg_start + 66;
+  int *seg_start = reinterpret_cast<int *>(contrib + 9 * CS), *seg_pt = seg_start + 66;
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
     const int nseg = __popcll(heads);
     const int nlive = __popcll(__ballot(live));
 #pragma unroll
-    for (int q = 0; q < 9; ++q) contrib[q * 64 + lane] = c9[q];
+    for (int q = 0; q < 9; ++q) contrib[q * CS + lane] = c9[q];
     if (head) {
       const int rank = __popcll(heads & ((1ull << lane) - 1ull));
       seg_start[rank] = lane;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
       if (sl < 7 && sg < nseg) {
         const int i0 = seg_start[sg], i1 = seg_start[sg + 1];
         double acc = 0.0;
-        for (int i = i0; i < i1; ++i) acc += contrib[comp * 64 + i];
+        for (int i = i0; i < i1; ++i) acc += contrib[comp * CS + i];
         // a point's observations may straddle two tiles: PL is zero-filled, partial sums add up
         atomicAdd(&PL[9 * (size_t)seg_pt[sg] + comp], acc);
       }
