@@ -961,9 +961,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   }
   h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7; h->ld = (h->D + 3) & ~3;
 
-  // Schur launch geometry: ~3000 blocks, >= 256 camera-list entries per block
+  // Schur launch geometry (measured sweep at config 3, profiles/): ~800 camera-list entries per
+  // block is the optimum (tail balance vs strip flush); small problems still get >= 2048 blocks
+  // as long as a block keeps >= 128 entries.
   const long long avg_len = std::max<long long>(1, nobs / m);
-  h->nchunks = (int)std::max<long long>(1, std::min<long long>((3072 + m - 1) / m, avg_len / 256));
+  h->nchunks = (int)std::max<long long>(1, std::max<long long>(avg_len / 800,
+                                                               std::min<long long>((2048 + m - 1) / m, avg_len / 128)));
   // tuning overrides (experiments only)
   if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(768, atoi(ev) / 64 * 64));
   if (const char *ev = getenv("MVBA_K1_THREADS")) h->k1_threads = std::max(64, std::min(512, atoi(ev) / 64 * 64));
