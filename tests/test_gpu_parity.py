@@ -297,3 +297,45 @@ def test_indefinite_reduced_system_takes_the_lu_path_like_numpy():
     # and the ordinary path is untouched afterwards
     E2, E2o = eng.try_step(1e-4), g.try_step(1e-4)
     assert eng.stats()["counts"]["lu_fallback"] == 1 and E2 == pytest.approx(E2o, rel=1e-9)
+
+
+def test_config4_shape_500_cameras_8_virtual_shards():
+    """BASELINE config 4's shape (500 cameras, 5 % visibility, points sharded 8 ways) at 1200 points:
+    the partial reduced systems of the 8 shards add up to the unsharded one, which matches the
+    oracle, and one LM step on the full problem agrees with the oracle (D = 4493, 3 strip segments)."""
+    from lib import _distributed as D
+
+    m = 500
+    sc = make_scene(1200, m, vis_p=0.05)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    f, u = sc.init_K[:, 0, 0], sc.init_K[:, :2, 2]
+    g = O.OracleEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    g.set_params(X, f, u, t, R)
+    g.linearize()
+    c = 1e-2
+    A, b = g.reduced_system(c)
+    E1o = g.try_step(c)
+    full = _mvba.HipEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    full.set_params(X, f, u, t, R)
+    full.linearize()
+    E1 = full.try_step(c)
+    m9 = 9 * m
+    Af = full.debug_read("A_full").reshape(m9, m9)
+    np.testing.assert_allclose(Af, A, rtol=0, atol=1e-11 * np.abs(A).max())
+    np.testing.assert_allclose(full.debug_read("b_full"), b, rtol=0, atol=1e-9 * np.abs(b).max())
+    dxi = np.zeros(m9); dxi[g.keep] = g.dxi_red
+    np.testing.assert_allclose(full.debug_read("dxi"), dxi, rtol=0, atol=1e-6 * np.abs(dxi).max())
+    assert E1 == pytest.approx(E1o, rel=1e-6)
+    As = np.zeros_like(Af)
+    for lo, hi in D.partition_points(sc.pt_ptr, 8):
+        p, cidx, x = D.slice_observations(sc.pt_ptr, sc.cam_idx, sc.xy, lo, hi)
+        e = _mvba.HipEngine(hi - lo, m, p, cidx, x, 1.0, sc.axis)
+        e.set_params(X[lo:hi], f, u, t, R)
+        e.linearize()
+        try:
+            e.try_step(c)  # a shard alone need not be positive definite / solvable: only A is wanted
+        except np.linalg.LinAlgError:
+            pass
+        As += e.debug_read("A_full").reshape(m9, m9)
+        e.close()
+    np.testing.assert_allclose(As, Af, rtol=0, atol=1e-12 * np.abs(Af).max())
