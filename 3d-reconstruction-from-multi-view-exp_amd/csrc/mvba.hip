@@ -924,7 +924,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     return fail(MVBA_ERR_BADARG, "bad problem sizes or null arrays (need n_images >= 2)");
   if (p->gauge_axis != 0 && p->gauge_axis != 1) return fail(MVBA_ERR_BADARG, "gauge_axis must be 0 or 1");
   if (p->pt_ptr[0] != 0 || p->pt_ptr[p->n_points] != p->n_obs) return fail(MVBA_ERR_BADARG, "pt_ptr does not span n_obs");
-  if (p->n_obs >= (1LL << 31)) return fail(MVBA_ERR_BADARG, "n_obs per handle must be < 2^31");
+  if (p->n_obs >= (1LL << 31) || p->n_points >= (1LL << 31))
+    return fail(MVBA_ERR_BADARG, "n_obs and n_points per handle must be < 2^31");
   const long long N = p->n_points, nobs = p->n_obs;
   const int m = p->n_images;
   // validate + build point-of-observation and the camera-major index
@@ -932,7 +933,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   std::vector<long long> csc_ptr(m + 1, 0);
   for (long long a = 0; a < N; ++a) {
     const long long o0 = p->pt_ptr[a], o1 = p->pt_ptr[a + 1];
-    if (o1 < o0) return fail(MVBA_ERR_BADARG, "pt_ptr not monotone");
+    if (o1 < o0 || o1 > nobs) return fail(MVBA_ERR_BADARG, "pt_ptr not monotone / out of range");
     for (long long o = o0; o < o1; ++o) {
       const int k = p->cam_idx[o];
       if (k < 0 || k >= m) return fail(MVBA_ERR_BADARG, "cam_idx out of range");
@@ -984,8 +985,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     }
   }
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
-  const int pt_blocks = (int)((N + 255) / 256);
-  h->n_partials = std::max(h->cost_grid, std::max(std::max(pt_blocks, 1), 4096));
+  h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks, k_backsub_cost at most 4096
 
 #define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
