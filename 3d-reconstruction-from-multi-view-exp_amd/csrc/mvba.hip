@@ -89,10 +89,11 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
                                                    const double2 *__restrict__ xy, double f0,
+                                                   const int *__restrict__ tile_start, int n_tiles,
                                                    double2 *__restrict__ rec, double *__restrict__ PL) {
   extern __shared__ double smem[];
   double *s_cam = smem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
   double2 *stage = reinterpret_cast<double2 *>(smem + ((m * CAM_LDS + 1) & ~1)) + wave * (64 * REC);
   // the same 8 KiB is reused for the per-point sums: contrib[9][CS] doubles (odd stride: the nine
@@ -102,11 +103,17 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
   int *seg_start = reinterpret_cast<int *>(contrib + 9 * CS), *seg_pt = seg_start + 66;
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long base = (long long)blockIdx.x * blockDim.x; base < nobs; base += stride) {
-    const long long wbase = base + 64 * wave;  // first observation of this wave's tile
+  // Wave tiles are POINT-ALIGNED (built once on the host): whole points packed greedily into at
+  // most 64 observations, so every per-point sum below is complete inside one wave -> plain
+  // stores, no atomics, bitwise-reproducible E_a / dP_a.  Only a point with more than 64
+  // observations is split over tiles (tile_start < 0 marks such a tile; its sums are added).
+  for (int tile = blockIdx.x * nwave + wave; tile < n_tiles; tile += gridDim.x * nwave) {
+    const int ts0 = tile_start[tile], ts1 = tile_start[tile + 1];
+    const bool split = ts0 < 0;
+    const long long wbase = split ? ~ts0 : ts0;  // first observation of this wave's tile
+    const int n = (int)((ts1 < 0 ? ~ts1 : ts1) - wbase);
     const long long o = wbase + lane;
-    const bool live = o < nobs;
+    const bool live = lane < n;
     int a = -1;
     double c9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
@@ -143,8 +150,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
     for (int q = 0; q < REC; ++q) {
       const int ol = q * 8 + (lane >> 3), pos = lane & 7;  // local observation, stored position
       const double2 v = stage[ol * REC + pos];
-      const long long og = wbase + ol;
-      if (og < nobs) rec[og * REC + (pos ^ (ol & 7))] = v;
+      if (ol < n) rec[(wbase + ol) * REC + (pos ^ (ol & 7))] = v;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- per-point sums (wave-level segmented reduction; observations are sorted by point)
@@ -152,7 +158,6 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
     const bool head = live && (lane == 0 || a != a_prev);
     const unsigned long long heads = __ballot(head);
     const int nseg = __popcll(heads);
-    const int nlive = __popcll(__ballot(live));
 #pragma unroll
     for (int q = 0; q < 9; ++q) contrib[q * CS + lane] = c9[q];
     if (head) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
       seg_start[rank] = lane;
       seg_pt[rank] = a;
     }
-    if (lane == 0) seg_start[nseg] = nlive;
+    if (lane == 0) seg_start[nseg] = n;
     __builtin_amdgcn_wave_barrier();
     const int sl = lane / 9, comp = lane - 9 * sl;
     for (int s0 = 0; s0 < nseg; s0 += 7) {
@@ -169,8 +174,9 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
         const int i0 = seg_start[sg], i1 = seg_start[sg + 1];
         double acc = 0.0;
         for (int i = i0; i < i1; ++i) acc += contrib[comp * CS + i];
-        // a point's observations may straddle two tiles: PL is zero-filled, partial sums add up
-        atomicAdd(&PL[9 * (size_t)seg_pt[sg] + comp], acc);
+        double *dst = &PL[9 * (size_t)seg_pt[sg] + comp];
+        if (split) atomicAdd(dst, acc);  // piece of a > 64-observation point: PL was zero-filled
+        else *dst = acc;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -787,6 +793,9 @@ struct mvba_handle {
   int *d_cam = nullptr, *d_obs_pt = nullptr;
   double2 *d_xy = nullptr;
   int4 *d_csc = nullptr;
+  int *d_tiles = nullptr;  // K1 point-aligned wave tiles
+  int n_tiles = 0;
+  bool any_split = false;
   long long *d_chunk_ptr = nullptr;
   int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768, k1_threads = 512;
   // state: [cur] committed, [1-cur] trial
@@ -951,6 +960,28 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         csc[fill[p->cam_idx[o]]++] = make_int4((int)o, (int)a, (int)(p->pt_ptr[a + 1] - o), 0);
   }
 
+  // K1 wave tiles: whole points packed greedily into <= 64 observations; a point with more than
+  // 64 observations is cut into pieces whose tiles are flagged by a complemented (negative) start
+  std::vector<int> tiles;
+  bool any_split = false;
+  {
+    long long cur0 = 0, fill = 0;
+    auto flush = [&](bool split_flag) { tiles.push_back(split_flag ? ~(int)cur0 : (int)cur0); };
+    for (long long a = 0; a < N; ++a) {
+      const long long d = p->pt_ptr[a + 1] - p->pt_ptr[a];
+      if (d > 64) {
+        if (fill) { flush(false); cur0 += fill; fill = 0; }
+        any_split = true;
+        for (long long q = 0; q < d; q += 64) { flush(true); cur0 += std::min<long long>(64, d - q); }
+        continue;
+      }
+      if (fill + d > 64) { flush(false); cur0 += fill; fill = 0; }
+      fill += d;
+    }
+    if (fill) { flush(false); cur0 += fill; }
+    tiles.push_back((int)nobs);  // terminator (never negative: only its magnitude is used)
+  }
+
   mvba_handle *h = new mvba_handle();
   if (p->device >= 0) {
     hipError_t e = hipSetDevice(p->device);
@@ -995,6 +1026,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_obs_pt, nobs));
   TRY(dmalloc(&h->d_xy, nobs));
   TRY(dmalloc(&h->d_csc, nobs));
+  h->n_tiles = (int)tiles.size() - 1;
+  h->any_split = any_split;
+  TRY(dmalloc(&h->d_tiles, tiles.size()));
   TRY(dmalloc(&h->d_chunk_ptr, chunk_ptr.size()));
   for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
   TRY(dmalloc(&h->d_rec, (size_t)REC * nobs));
@@ -1018,6 +1052,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
   }
+  TRYH(hipMemcpy(h->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+  // points without observations are never written by K1: their blocks stay zero (-> singular, ref :128)
+  TRYH(hipMemset(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(N, 1)));
   TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   // opt in to large dynamic LDS
@@ -1041,7 +1078,7 @@ void mvba_destroy(mvba_handle *h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
-  void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
+  void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
@@ -1101,14 +1138,16 @@ int mvba_linearize(mvba_handle *h) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
   MVBA_HIP(hipSetDevice(h->device));
-  MVBA_HIP(hipMemsetAsync(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(h->N, 1), h->stream));
+  if (h->any_split)  // only pieces of > 64-observation points are accumulated with atomics
+    MVBA_HIP(hipMemsetAsync(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(h->N, 1), h->stream));
   if (h->nobs) {
     Timed t(h, MVBA_K_RESID_JAC);  // K1 with K2 (per-point blocks) fused in
     const int kt = h->k1_threads;  // 8 waves share one camera table: 2 blocks = 16 waves per CU
     const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + (kt / 64) * 64 * 2 * REC) * sizeof(double);
-    const int grid = (int)std::min<long long>(2048 * 256 / kt, (h->nobs + kt - 1) / kt);
+    const int wpb = kt / 64;
+    const int grid = std::max(1, std::min(2048 * 256 / kt, (h->n_tiles + wpb - 1) / wpb));
     hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(kt), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
-                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_rec, h->d_PL);
+                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_tiles, h->n_tiles, h->d_rec, h->d_PL);
   }
   MVBA_HIP(hipGetLastError());
   h->linearized = true; h->have_trial = false;

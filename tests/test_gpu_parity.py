@@ -114,7 +114,7 @@ def test_default_scene_headline_numbers(golden):
     assert np.sqrt(log[-1]["reprojection_error"] / 2000) == pytest.approx(0.0063291001035384233, abs=1e-9)
 
 
-@pytest.mark.parametrize("n,m,p", [(2000, 12, 0.4), (777, 33, 0.15), (1500, 5, 1.0)])
+@pytest.mark.parametrize("n,m,p", [(2000, 12, 0.4), (777, 33, 0.15), (1500, 5, 1.0), (90, 70, 1.0)])  # last: 70 obs/point > one 64-lane K1 tile
 def test_random_scene_one_step_and_short_run_vs_oracle(n, m, p, capsys):
     sc = make_scene(n, m, vis_p=p)
     ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
