@@ -423,7 +423,7 @@ __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__
   const int gi = keep_index(i, gauge_axis);
   // only the upper block triangle is stored: read (min,max) from the packed strips
   const int r = min(gi, gj), c = max(gi, gj);
-  const int k = r / 9, l = c / 9;
+  const int k = r / 9;
   M[(size_t)i * ld + j] = Afull[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
 }
 
@@ -432,22 +432,32 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// One wave per 64 rows.  Lane r (mod 32) keeps row r of the diagonal tile in registers;
-// entries of L are broadcast with v_readlane (SGPR operands): no LDS, no barriers, every
-// index static.  Every wave re-factors the tile (cheap) so the panel needs one launch.
+typedef double mvba_d4 __attribute__((ext_vector_type(4)));
+
+// One wave per 64 rows below the tile.  Lanes 0..31 keep row r of the diagonal tile in
+// registers, lanes 32..63 row r of the IDENTITY: the column operations of the factorisation
+// (entries of L broadcast with v_readlane: no LDS, no barriers, every index static) turn the
+// identity rows into L^-T.  The rows below the tile are then X = P L^-T as a 64x32x32 f64 MFMA
+// product (L^-T staged in LDS in B-operand order) instead of a second 496-deep substitution
+// chain.  Every wave re-factors the tile (cheap) so the panel needs one launch; the factored
+// tile goes to its own buffer (Ltile, read by the back-substitution) so that no wave can
+// read a tile another wave has already overwritten.
 __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int ld, int D, int j0, int nb,
-                                                   double *__restrict__ dinv, int *__restrict__ flag) {
+                                                   double *__restrict__ dinv, double *__restrict__ Ltile,
+                                                   int *__restrict__ flag) {
+  __shared__ double Zt[NB][NB + 1];  // Zt[k][c] = (L^-T)[k][c], upper triangular
   const int lane = threadIdx.x;
   const int r = lane & 31;
+  const bool ident = lane >= 32;
   double a[NB];
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    double v = (r == c) ? 1.0 : 0.0;  // identity padding beyond nb
-    if (r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c];
+    double v = (r == c) ? 1.0 : 0.0;  // identity rows, and identity padding beyond nb
+    if (!ident && r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c];
     a[c] = v;
   }
   bool bad = false;
-  double rinv[NB];
+  double my_rinv = 0.0;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     const double piv = readlane_d(a[k], k);
@@ -457,41 +467,62 @@ __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int l
     double y = __builtin_amdgcn_rsq(piv);
     y = y * (1.5 - 0.5 * piv * y * y);
     y = y * (1.5 - 0.5 * piv * y * y);
-    rinv[k] = y;
-    a[k] = (r == k) ? piv * y : a[k] * y;
-    // entries above the diagonal (c > r) hold garbage that is never read: no predicate needed
+    if (lane == k) my_rinv = y;
+    a[k] = (lane == k) ? piv * y : a[k] * y;
+    // tile entries above the diagonal (c > r) hold garbage that is never read: no predicate needed
 #pragma unroll
     for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
   }
   if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-  if (blockIdx.x == 0 && lane < NB && r < nb) {
+  if (blockIdx.x == 0 && !ident && r < nb) {
 #pragma unroll
     for (int c = 0; c < NB; ++c)
-      if (c <= r && c < nb) M[(size_t)(j0 + r) * ld + j0 + c] = a[c];
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c == r) dinv[j0 + r] = rinv[c];  // reciprocal diagonal for the back-substitution
+      if (c <= r && c < nb) Ltile[r * NB + c] = a[c];
+    dinv[j0 + r] = my_rinv;  // reciprocal diagonal for the back-substitution
   }
-  // rows below the tile (row D = rhs included): X L^T = P, one row per lane
-  const int row = j0 + nb + blockIdx.x * 64 + lane;
-  const bool live = row <= D;
-  double x[NB];
+  if (ident) {
 #pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = (live && c < nb) ? M[(size_t)row * ld + j0 + c] : 0.0;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    x[k] = x[k] * rinv[k];
-#pragma unroll
-    for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * readlane_d(a[k], c);
+    for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
   }
-  if (live) {
+  __syncthreads();
+  // rows below the tile (row D = rhs included): X = P Zt.  A operand: lane l holds
+  // P[row0 + (l & 15)][4 t + (l >> 4)]; B operand Zt[4 t + (l >> 4)][c0 + (l & 15)];
+  // C/D: col = l & 15, row = (l >> 4) + 4 reg.  Zt[k][c] = 0 for k > c: the left column tile
+  // needs only t < 4.
+  const int li = lane & 15, lk = lane >> 4;
+  double bz[NB / 4][2];
 #pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c < nb) M[(size_t)row * ld + j0 + c] = x[c];
+  for (int t = 0; t < NB / 4; ++t) {
+    bz[t][0] = Zt[4 * t + lk][li];
+    bz[t][1] = Zt[4 * t + lk][16 + li];
+  }
+  const int rowbase = j0 + nb + blockIdx.x * 64;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    if (rowbase + 16 * rt > D) break;  // wave-uniform
+    const int rowA = rowbase + 16 * rt + li;
+    const double *prow = M + (size_t)min(rowA, D) * ld + j0;
+    double av[NB / 4];
+#pragma unroll
+    for (int t = 0; t < NB / 4; ++t) av[t] = (rowA <= D && 4 * t + lk < nb) ? prow[4 * t + lk] : 0.0;
+    mvba_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NB / 4; ++t) {
+      if (t < NB / 8) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bz[t][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bz[t][1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rowS = rowbase + 16 * rt + lk + 4 * q;
+      if (rowS <= D) {
+        double *dst = M + (size_t)rowS * ld + j0;
+        if (li < nb) dst[li] = acc0[q];
+        if (16 + li < nb) dst[16 + li] = acc1[q];
+      }
+    }
   }
 }
 
-typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 
 // Trailing update with f64 MFMA.  Block = 4 waves = 64x64 output tile, wave = 32x32.
 // A operand: lane l holds P[row0 + (l & 15)][k = 4 kk + (l >> 4)]; B operand the same
@@ -539,6 +570,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 // update y[c] -= sum_r L[jb+r][c] x[jb+r] in flight.
 __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restrict__ M, int ld, int D, int m,
                                                          int gauge_axis, const double *__restrict__ dinv,
+                                                         const double *__restrict__ Ltiles,
                                                          double *__restrict__ dxi_full) {
   extern __shared__ double y[];  // D + NB doubles (zero tail: the last block may be partial)
   __shared__ double T[NB][NB + 1];
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restric
     const int jb = bi * NB, nb = min(NB, D - jb);
     {
       const int r = tid / NB, c = tid % NB;  // 1024 threads = one tile
-      T[r][c] = (r < nb && c < r) ? M[(size_t)(jb + r) * ld + jb + c] : 0.0;
+      T[r][c] = (r < nb && c < r) ? Ltiles[(size_t)bi * NB * NB + r * NB + c] : 0.0;
     }
     // operands of this block's update, one column c per thread (rows jb..jb+nb-1 of L)
     double lcol[NB];
@@ -806,7 +838,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_Ltiles = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -1038,6 +1070,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
   TRY(dmalloc(&h->d_dinv, h->D + NB));
+  TRY(dmalloc(&h->d_Ltiles, (size_t)((h->D + NB - 1) / NB) * NB * NB));
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
   TRY(dmalloc(&h->d_partials, h->n_partials));
@@ -1079,7 +1112,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv, h->d_lu,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv, h->d_Ltiles, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -1191,14 +1224,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const int nb = std::min(NB, D - j0);
       const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
       hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(64), 0, h->stream, h->d_Ared, ld, D, j0, nb,
-                         h->d_dinv, h->d_flag);
+                         h->d_dinv, h->d_Ltiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
       if (j0 + nb < D) {
         const int nt = (rows_below + 63) / 64;
         hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, j0);
       }
     }
     hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), (D + NB) * sizeof(double), h->stream, h->d_Ared, ld, D, m,
-                       h->gauge_axis, h->d_dinv, h->d_dxi);
+                       h->gauge_axis, h->d_dinv, h->d_Ltiles, h->d_dxi);
   }
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
