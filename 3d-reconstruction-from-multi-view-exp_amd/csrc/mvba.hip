@@ -439,12 +439,11 @@ typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 // (entries of L broadcast with v_readlane: no LDS, no barriers, every index static) turn the
 // identity rows into L^-T.  The rows below the tile are then X = P L^-T as a 64x32x32 f64 MFMA
 // product (L^-T staged in LDS in B-operand order) instead of a second 496-deep substitution
-// chain.  Every wave re-factors the tile (cheap) so the panel needs one launch; the factored
-// tile goes to its own buffer (Ltile, read by the back-substitution) so that no wave can
-// read a tile another wave has already overwritten.
+// chain.  Every wave re-factors the tile (cheap) so the panel needs one launch.  The tile in M
+// is left untouched (other waves may still be reading it); what the back-substitution needs is
+// L^-T of the tile, which goes to its own buffer (Ztile).
 __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int ld, int D, int j0, int nb,
-                                                   double *__restrict__ dinv, double *__restrict__ Ltile,
-                                                   int *__restrict__ flag) {
+                                                   double *__restrict__ Ztile, int *__restrict__ flag) {
   __shared__ double Zt[NB][NB + 1];  // Zt[k][c] = (L^-T)[k][c], upper triangular
   const int lane = threadIdx.x;
   const int r = lane & 31;
@@ -457,7 +456,6 @@ __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int l
     a[c] = v;
   }
   bool bad = false;
-  double my_rinv = 0.0;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     const double piv = readlane_d(a[k], k);
@@ -467,18 +465,16 @@ __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int l
     double y = __builtin_amdgcn_rsq(piv);
     y = y * (1.5 - 0.5 * piv * y * y);
     y = y * (1.5 - 0.5 * piv * y * y);
-    if (lane == k) my_rinv = y;
     a[k] = (lane == k) ? piv * y : a[k] * y;
     // tile entries above the diagonal (c > r) hold garbage that is never read: no predicate needed
 #pragma unroll
     for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
   }
   if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-  if (blockIdx.x == 0 && !ident && r < nb) {
+  if (blockIdx.x == 0 && ident && r < nb) {
 #pragma unroll
     for (int c = 0; c < NB; ++c)
-      if (c <= r && c < nb) Ltile[r * NB + c] = a[c];
-    dinv[j0 + r] = my_rinv;  // reciprocal diagonal for the back-substitution
+      if (c >= r && c < nb) Ztile[r * NB + c] = a[c];
   }
   if (ident) {
 #pragma unroll
@@ -565,12 +561,11 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 }
 
 // L^T x = y (y = row D), single workgroup; scatter x into the full 9m vector (zeros at the gauge slots).
-// Per 32-column block: wave 0 solves the diagonal tile from LDS with reciprocal diagonals (no
-// divides on the serial path) while every thread already has the operands of the following
-// update y[c] -= sum_r L[jb+r][c] x[jb+r] in flight.
+// Per 32-column block: x_blk = (L^-T tile) y_blk is a 32x32 mat-vec on wave 0 (the tiles come
+// from k_chol_panel: no serial substitution) while every thread already has the operands of the
+// following update y[c] -= sum_r L[jb+r][c] x[jb+r] in flight.
 __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restrict__ M, int ld, int D, int m,
-                                                         int gauge_axis, const double *__restrict__ dinv,
-                                                         const double *__restrict__ Ltiles,
+                                                         int gauge_axis, const double *__restrict__ Ztiles,
                                                          double *__restrict__ dxi_full) {
   extern __shared__ double y[];  // D + NB doubles (zero tail: the last block may be partial)
   __shared__ double T[NB][NB + 1];
@@ -583,7 +578,7 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restric
     const int jb = bi * NB, nb = min(NB, D - jb);
     {
       const int r = tid / NB, c = tid % NB;  // 1024 threads = one tile
-      T[r][c] = (r < nb && c < r) ? Ltiles[(size_t)bi * NB * NB + r * NB + c] : 0.0;
+      T[r][c] = (r < nb && c >= r && c < nb) ? Ztiles[(size_t)bi * NB * NB + r * NB + c] : 0.0;
     }
     // operands of this block's update, one column c per thread (rows jb..jb+nb-1 of L)
     double lcol[NB];
@@ -592,14 +587,16 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restric
     for (int r = 0; r < NB; ++r) lcol[r] = (cc < jb && r < nb) ? M[(size_t)(jb + r) * ld + cc] : 0.0;
     __syncthreads();
     if (wave == 0) {
-      double xr = (lane < nb) ? y[jb + lane] : 0.0;
-      const double di = (lane < nb) ? dinv[jb + lane] : 0.0;
-      for (int k = nb - 1; k >= 0; --k) {
-        const double xk = __shfl(xr * di, k, 64);
-        if (lane == k) xr = xk;
-        if (lane < k) xr -= T[k][lane] * xk;
+      const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < NB / 2; q += 2) {
+        s0 += T[r][16 * h + q] * y[jb + 16 * h + q];
+        s1 += T[r][16 * h + q + 1] * y[jb + 16 * h + q + 1];
       }
-      if (lane < nb) y[jb + lane] = xr;
+      double xr = s0 + s1;
+      xr += __shfl_xor(xr, 32, 64);
+      if (lane < nb) y[jb + lane] = xr;  // all reads of y above precede this write (one wave, in order)
     }
     __syncthreads();
     if (cc < jb) {
@@ -838,7 +835,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_dinv = nullptr, *d_Ltiles = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_Ztiles = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -1069,8 +1066,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
-  TRY(dmalloc(&h->d_dinv, h->D + NB));
-  TRY(dmalloc(&h->d_Ltiles, (size_t)((h->D + NB - 1) / NB) * NB * NB));
+  TRY(dmalloc(&h->d_Ztiles, (size_t)((h->D + NB - 1) / NB) * NB * NB));
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
   TRY(dmalloc(&h->d_partials, h->n_partials));
@@ -1112,7 +1108,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_dinv, h->d_Ltiles, h->d_lu,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -1224,14 +1220,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const int nb = std::min(NB, D - j0);
       const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
       hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(64), 0, h->stream, h->d_Ared, ld, D, j0, nb,
-                         h->d_dinv, h->d_Ltiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
+                         h->d_Ztiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
       if (j0 + nb < D) {
         const int nt = (rows_below + 63) / 64;
         hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, j0);
       }
     }
     hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), (D + NB) * sizeof(double), h->stream, h->d_Ared, ld, D, m,
-                       h->gauge_axis, h->d_dinv, h->d_Ltiles, h->d_dxi);
+                       h->gauge_axis, h->d_Ztiles, h->d_dxi);
   }
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
