@@ -403,12 +403,18 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
 // the reference's np.linalg.solve (LU, ref :146) is replaced by a blocked Cholesky
 // (parity-safe).  Storage: M = (D+1) x ld row-major, lower triangle of A in
 // rows 0..D-1 and the right-hand side b as ROW D, so that factorising carries the forward
-// substitution along (row D ends up holding y = L^-1 b).  Per 32-column panel:
-//   k_chol_panel  one wave per 64 rows: every wave re-factors the 32x32 diagonal tile in
-//                 LDS (wave-synchronous, no barriers), then solves X L^T = P for its rows
-//   k_chol_trail  trailing update C -= P P^T on v_mfma_f64_16x16x4_f64, 32x32 per wave
-// then k_chol_backsolve does L^T x = y in one workgroup with LDS-staged tiles.
+// substitution along (row D ends up holding y = L^-1 b).  Two-level blocking: columns are
+// processed in super-blocks of SBW = 128 (four 32-column panels).
+//   k_chol_panel  workgroup = 4 waves per 64 rows below the tile.  Left-looking inside the
+//                 super-block: the tile and the rows are first updated with the super-block's
+//                 earlier panels (f64 MFMA, K <= 96); wave 0 factors the 32x32 tile in
+//                 registers (identity rows alongside give L^-T); the rows are X = P L^-T (MFMA)
+//   k_chol_trail  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
+//                 everything right of the super-block (4x less read-modify-write traffic on C
+//                 than a per-panel update, and 4x fewer launches on the critical path)
+// then k_chol_backsolve does L^T x = y in one workgroup from the L^-T tiles.
 constexpr int NB = 32;
+constexpr int SBW = 4 * NB;
 
 __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
                           const double *__restrict__ bfull, double *__restrict__ M) {
@@ -434,100 +440,148 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 
 typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 
-// One wave per 64 rows below the tile.  Lanes 0..31 keep row r of the diagonal tile in
-// registers, lanes 32..63 row r of the IDENTITY: the column operations of the factorisation
-// (entries of L broadcast with v_readlane: no LDS, no barriers, every index static) turn the
-// identity rows into L^-T.  The rows below the tile are then X = P L^-T as a 64x32x32 f64 MFMA
-// product (L^-T staged in LDS in B-operand order) instead of a second 496-deep substitution
-// chain.  Every wave re-factors the tile (cheap) so the panel needs one launch.  The tile in M
-// is left untouched (other waves may still be reading it); what the back-substitution needs is
-// L^-T of the tile, which goes to its own buffer (Ztile).
-__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ M, int ld, int D, int j0, int nb,
-                                                   double *__restrict__ Ztile, int *__restrict__ flag) {
+// MFMA operands straight from row-major rows: the product sums over k, so any permutation of k
+// that A and B share is allowed.  Lane (idx = l & 15, kq = l >> 4) loads the 4 CONSECUTIVE
+// doubles X[idx][16 g + 4 kq .. + 3] (one 32-byte load; a row's 16-column group is one full
+// 128-byte line across kq) and feeds element u to MFMA step 4 g + u.
+__device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
+  return live ? *reinterpret_cast<const mvba_d4 *>(p) : mvba_d4{0.0, 0.0, 0.0, 0.0};
+}
+
+// Left-looking update of one panel workgroup with G16 16-column groups of earlier panels.
+// All loads are issued before the first MFMA: one memory latency per panel.
+template <int G16>
+__device__ __forceinline__ void panel_update(const double *pa, const double *p0, const double *p1, bool liveA, bool live0,
+                                             bool live1, int wave, mvba_d4 &accO0, mvba_d4 &accO1, mvba_d4 &accD) {
+  mvba_d4 a[G16], b0[G16], b1[G16];
+#pragma unroll
+  for (int g = 0; g < G16; ++g) {
+    a[g] = load_k4(pa + 16 * g, liveA);
+    b0[g] = load_k4(p0 + 16 * g, live0);
+    b1[g] = load_k4(p1 + 16 * g, live1);
+  }
+#pragma unroll
+  for (int g = 0; g < G16; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      accO0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][u], b0[g][u], accO0, 0, 0, 0);
+      accO1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][u], b1[g][u], accO1, 0, 0, 0);
+      if (wave < 3)
+        accD = __builtin_amdgcn_mfma_f64_16x16x4f64(wave == 0 ? b0[g][u] : b1[g][u], wave == 2 ? b1[g][u] : b0[g][u], accD, 0, 0, 0);
+    }
+}
+
+// Workgroup = 4 waves = 64 rows below the tile (wave w: rows 16w..16w+15).
+//  A. left-looking update with the super-block's earlier columns [jS, j0): own rows x tile rows
+//     (two 16x16 MFMA tiles per wave) and the tile itself (its three lower 16x16 tiles on
+//     waves 0..2); results go to LDS (Pt, Td).
+//  B. wave 0: lanes 0..31 keep row r of the tile in registers, lanes 32..63 row r of the
+//     IDENTITY: the column operations of the factorisation (entries of L broadcast with
+//     v_readlane: no LDS, every index static) turn the identity rows into L^-T  -> LDS (Zt).
+//  C. rows below: X = P L^-T as MFMA products instead of a 496-deep substitution chain.
+// Every workgroup re-factors the tile (cheap) so the panel needs one launch.  The tile in M
+// is left untouched (other workgroups may still be reading it); what the back-substitution
+// needs is L^-T of the tile, which goes to its own buffer (Ztile).
+// MFMA operand layouts: A/B lane l holds X[idx = l & 15][k = 4 t + (l >> 4)];
+// C/D: col = l & 15, row = (l >> 4) + 4 reg.
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ M, int ld, int D, int jS, int j0, int nb,
+                                                    double *__restrict__ Ztile, int *__restrict__ flag) {
+  __shared__ double Td[NB][NB + 1];  // updated diagonal tile (lower triangle + identity padding)
   __shared__ double Zt[NB][NB + 1];  // Zt[k][c] = (L^-T)[k][c], upper triangular
-  const int lane = threadIdx.x;
-  const int r = lane & 31;
-  const bool ident = lane >= 32;
-  double a[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double v = (r == c) ? 1.0 : 0.0;  // identity rows, and identity padding beyond nb
-    if (!ident && r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c];
-    a[c] = v;
-  }
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const double piv = readlane_d(a[k], k);
-    bad |= !(piv > 0.0);
-    // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
-    // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
-    double y = __builtin_amdgcn_rsq(piv);
-    y = y * (1.5 - 0.5 * piv * y * y);
-    y = y * (1.5 - 0.5 * piv * y * y);
-    a[k] = (lane == k) ? piv * y : a[k] * y;
-    // tile entries above the diagonal (c > r) hold garbage that is never read: no predicate needed
-#pragma unroll
-    for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
-  }
-  if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-  if (blockIdx.x == 0 && ident && r < nb) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c >= r && c < nb) Ztile[r * NB + c] = a[c];
-  }
-  if (ident) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
-  }
-  __syncthreads();
-  // rows below the tile (row D = rhs included): X = P Zt.  A operand: lane l holds
-  // P[row0 + (l & 15)][4 t + (l >> 4)]; B operand Zt[4 t + (l >> 4)][c0 + (l & 15)];
-  // C/D: col = l & 15, row = (l >> 4) + 4 reg.  Zt[k][c] = 0 for k > c: the left column tile
-  // needs only t < 4.
+  __shared__ double Pt[64][NB + 1];  // updated rows below the tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  double bz[NB / 4][2];
-#pragma unroll
-  for (int t = 0; t < NB / 4; ++t) {
-    bz[t][0] = Zt[4 * t + lk][li];
-    bz[t][1] = Zt[4 * t + lk][16 + li];
-  }
-  const int rowbase = j0 + nb + blockIdx.x * 64;
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    if (rowbase + 16 * rt > D) break;  // wave-uniform
-    const int rowA = rowbase + 16 * rt + li;
-    const double *prow = M + (size_t)min(rowA, D) * ld + j0;
-    double av[NB / 4];
-#pragma unroll
-    for (int t = 0; t < NB / 4; ++t) av[t] = (rowA <= D && 4 * t + lk < nb) ? prow[4 * t + lk] : 0.0;
-    mvba_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NB / 4; ++t) {
-      if (t < NB / 8) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bz[t][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bz[t][1], acc1, 0, 0, 0);
+  const int rowbase = j0 + nb + blockIdx.x * 64 + 16 * wave;
+  const mvba_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  // ---- A
+  {
+    mvba_d4 accO0 = zero4, accO1 = zero4, accD = zero4;
+    const int rowA = rowbase + li;
+    const bool liveA = rowA <= D, live0 = li < nb, live1 = 16 + li < nb;
+    const double *pa = M + (size_t)min(rowA, D) * ld + jS + 4 * lk;
+    const double *p0 = M + (size_t)(j0 + (live0 ? li : 0)) * ld + jS + 4 * lk;
+    const double *p1 = M + (size_t)(j0 + (live1 ? 16 + li : 0)) * ld + jS + 4 * lk;
+    switch ((j0 - jS) / NB) {
+      case 1: panel_update<2>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
+      case 2: panel_update<4>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
+      case 3: panel_update<6>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
+      default: break;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int rowS = rowbase + 16 * rt + lk + 4 * q;
-      if (rowS <= D) {
-        double *dst = M + (size_t)rowS * ld + j0;
-        if (li < nb) dst[li] = acc0[q];
-        if (16 + li < nb) dst[16 + li] = acc1[q];
+      const int rl = lk + 4 * q, row = rowbase + rl;
+      const double *src = M + (size_t)min(row, D) * ld + j0;
+      Pt[16 * wave + rl][li] = (row <= D && li < nb) ? src[li] - accO0[q] : 0.0;
+      Pt[16 * wave + rl][16 + li] = (row <= D && 16 + li < nb) ? src[16 + li] - accO1[q] : 0.0;
+      // diagonal tile: waves 0, 1, 2 hold tiles (0,0), (1,0), (1,1); wave 3 clears (0,1)
+      const int r = ((wave == 1 || wave == 2) ? 16 : 0) + rl, c = ((wave >= 2) ? 16 : 0) + li;
+      double v = (r == c) ? 1.0 : 0.0;  // identity padding beyond nb
+      if (wave < 3 && r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c] - accD[q];
+      Td[r][c] = v;
+    }
+  }
+  __syncthreads();
+  // ---- B
+  if (wave == 0) {
+    const int r = lane & 31;
+    const bool ident = lane >= 32;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : Td[r][c];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const double piv = readlane_d(a[k], k);
+      bad |= !(piv > 0.0);
+      // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
+      // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
+      double y = __builtin_amdgcn_rsq(piv);
+      y = y * (1.5 - 0.5 * piv * y * y);
+      y = y * (1.5 - 0.5 * piv * y * y);
+      a[k] = (lane == k) ? piv * y : a[k] * y;
+      // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
+#pragma unroll
+      for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
+    }
+    if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+    if (ident) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
+      if (blockIdx.x == 0 && r < nb) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c >= r && c < nb) Ztile[r * NB + c] = a[c];
       }
+    }
+  }
+  __syncthreads();
+  // ---- C: X = P Zt for this wave's 16 rows.  Zt[k][c] = 0 for k > c: the left column tile
+  // needs only t < 4.
+  if (rowbase > D) return;
+  mvba_d4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+  for (int t = 0; t < NB / 4; ++t) {
+    const double av = Pt[16 * wave + li][4 * t + lk];
+    if (t < NB / 8) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[4 * t + lk][li], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[4 * t + lk][16 + li], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = rowbase + lk + 4 * q;
+    if (row <= D) {
+      double *dst = M + (size_t)row * ld + j0;
+      if (li < nb) dst[li] = acc0[q];
+      if (16 + li < nb) dst[16 + li] = acc1[q];
     }
   }
 }
 
-
-// Trailing update with f64 MFMA.  Block = 4 waves = 64x64 output tile, wave = 32x32.
-// A operand: lane l holds P[row0 + (l & 15)][k = 4 kk + (l >> 4)]; B operand the same
-// from the column tile (B[k][n] = P[col0 + n][k]); C/D: col = l & 15, row = (l >> 4) + 4 reg.
-__global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int ld, int D, int j0) {
-  const int t0 = j0 + NB;
+// Trailing update with f64 MFMA for the finished super-block [jS, jE): C -= P P^T on rows/cols
+// >= jE (jE - jS == SBW).  Block = 4 waves = 64x64 output tile, wave = 32x32.
+__global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int ld, int D, int jS, int jE) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = t0 + blockIdx.y * 64 + (wave >> 1) * 32;
-  const int c0 = t0 + blockIdx.x * 64 + (wave & 1) * 32;
+  const int r0 = jE + blockIdx.y * 64 + (wave >> 1) * 32;
+  const int c0 = jE + blockIdx.x * 64 + (wave & 1) * 32;
   if (c0 > r0 + 31 || r0 > D || c0 >= D) return;  // strictly upper tile or out of range
   mvba_d4 acc[2][2];
 #pragma unroll
@@ -535,20 +589,27 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lk = lane >> 4;
+  mvba_d4 av[SBW / 16][2], bv[SBW / 16][2];  // jE - jS == SBW: every load is issued before the first MFMA
 #pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    double av[2], bv[2];
+  for (int i = 0; i < 2; ++i) {
+    const int rr = r0 + 16 * i + li, cc = c0 + 16 * i + li;
+    const double *pa = M + (size_t)min(rr, D) * ld + jS + 4 * lk;
+    const double *pb = M + (size_t)min(cc, D) * ld + jS + 4 * lk;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rr = r0 + 16 * i + li, cc = c0 + 16 * i + li;
-      av[i] = (rr <= D) ? M[(size_t)rr * ld + j0 + 4 * kk + lk] : 0.0;
-      bv[i] = (cc < D) ? M[(size_t)cc * ld + j0 + 4 * kk + lk] : 0.0;
+    for (int g = 0; g < SBW / 16; ++g) {
+      av[g][i] = load_k4(pa + 16 * g, rr <= D);
+      bv[g][i] = load_k4(pb + 16 * g, cc < D);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
   }
+#pragma unroll
+  for (int g = 0; g < SBW / 16; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][i][u], bv[g][j][u], acc[i][j], 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1216,14 +1277,17 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int ld = h->ld;
     hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
                        h->d_Ared);
-    for (int j0 = 0; j0 < D; j0 += NB) {
-      const int nb = std::min(NB, D - j0);
-      const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
-      hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(64), 0, h->stream, h->d_Ared, ld, D, j0, nb,
-                         h->d_Ztiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
-      if (j0 + nb < D) {
-        const int nt = (rows_below + 63) / 64;
-        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, j0);
+    for (int jS = 0; jS < D; jS += SBW) {
+      const int jE = std::min(jS + SBW, D);
+      for (int j0 = jS; j0 < jE; j0 += NB) {
+        const int nb = std::min(NB, D - j0);
+        const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
+        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, j0, nb,
+                           h->d_Ztiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
+      }
+      if (jE < D) {
+        const int nt = (D + 1 - jE + 63) / 64;
+        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
     hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), (D + NB) * sizeof(double), h->stream, h->d_Ared, ld, D, m,
