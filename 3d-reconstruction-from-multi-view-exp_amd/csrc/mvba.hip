@@ -589,27 +589,38 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lk = lane >> 4;
-  mvba_d4 av[SBW / 16][2], bv[SBW / 16][2];  // jE - jS == SBW: every load is issued before the first MFMA
+  // jE - jS == SBW, consumed in two halves of 64 columns: all 16 loads of a half are issued before
+  // its first MFMA (two memory latencies per wave, ~170 VGPRs -> 3 waves per SIMD hide them)
+  const double *pa[2], *pb[2];
+  bool la[2], lb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rr = r0 + 16 * i + li, cc = c0 + 16 * i + li;
-    const double *pa = M + (size_t)min(rr, D) * ld + jS + 4 * lk;
-    const double *pb = M + (size_t)min(cc, D) * ld + jS + 4 * lk;
-#pragma unroll
-    for (int g = 0; g < SBW / 16; ++g) {
-      av[g][i] = load_k4(pa + 16 * g, rr <= D);
-      bv[g][i] = load_k4(pb + 16 * g, cc < D);
-    }
+    la[i] = rr <= D;
+    lb[i] = cc < D;
+    pa[i] = M + (size_t)min(rr, D) * ld + jS + 4 * lk;
+    pb[i] = M + (size_t)min(cc, D) * ld + jS + 4 * lk;
   }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    mvba_d4 av[SBW / 32][2], bv[SBW / 32][2];
 #pragma unroll
-  for (int g = 0; g < SBW / 16; ++g)
+    for (int g = 0; g < SBW / 32; ++g)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+      for (int i = 0; i < 2; ++i) {
+        av[g][i] = load_k4(pa[i] + 16 * (g + half * (SBW / 32)), la[i]);
+        bv[g][i] = load_k4(pb[i] + 16 * (g + half * (SBW / 32)), lb[i]);
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < SBW / 32; ++g)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][i][u], bv[g][j][u], acc[i][j], 0, 0, 0);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][i][u], bv[g][j][u], acc[i][j], 0, 0, 0);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -621,59 +632,101 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
       }
 }
 
-// L^T x = y (y = row D), single workgroup; scatter x into the full 9m vector (zeros at the gauge slots).
-// Per 32-column block: x_blk = (L^-T tile) y_blk is a 32x32 mat-vec on wave 0 (the tiles come
-// from k_chol_panel: no serial substitution) while every thread already has the operands of the
-// following update y[c] -= sum_r L[jb+r][c] x[jb+r] in flight.
-__global__ __launch_bounds__(1024) void k_chol_backsolve(const double *__restrict__ M, int ld, int D, int m,
-                                                         int gauge_axis, const double *__restrict__ Ztiles,
-                                                         double *__restrict__ dxi_full) {
-  extern __shared__ double y[];  // D + NB doubles (zero tail: the last block may be partial)
+// L^T x = y (y = row D of M, overwritten by x), one launch per 128-column super-block, last one
+// first.  Launch for super-block [jS, jE), given the finished x of the super-block above it
+// [jE, jE2):
+//   workgroups >= 1   y[c] -= sum_r L[r][c] x[r]  (r in [jE, jE2)) for the columns c < jS, one column
+//                     per thread, rows read coalesced: the bulk of the memory traffic, chip-wide
+//   workgroup 0       the same for its own columns [jS, jE), then the four tiles from the top:
+//                     x_t = (L^-T tile) y_t is a 32x32 mat-vec (tiles from k_chol_panel: no serial
+//                     substitution) and y -= L[tile rows][cols left of it in the super-block]^T x_t;
+//                     scatters x into the full 9m vector (zeros at the gauge slots).
+__global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, int ld, int D, int m, int gauge_axis,
+                                                        const double *__restrict__ Ztiles, double *__restrict__ dxi_full,
+                                                        int jS, int jE, int jE2) {
+  __shared__ double xp[SBW];  // x of the super-block above
+  __shared__ double ys[SBW];  // y, then x, of this super-block
+  __shared__ double part[2][SBW];
   __shared__ double T[NB][NB + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < D + NB; i += blockDim.x) y[i] = (i < D) ? M[(size_t)D * ld + i] : 0.0;
-  for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
+  double *y = M + (size_t)D * ld;
+  const int tid = threadIdx.x;
+  const int np = jE2 - jE;  // 0 for the first launch (top super-block)
+  if (tid < SBW) xp[tid] = (tid < np) ? y[jE + tid] : 0.0;
   __syncthreads();
-  const int nblk = (D + NB - 1) / NB;
-  for (int bi = nblk - 1; bi >= 0; --bi) {
-    const int jb = bi * NB, nb = min(NB, D - jb);
-    {
-      const int r = tid / NB, c = tid % NB;  // 1024 threads = one tile
-      T[r][c] = (r < nb && c >= r && c < nb) ? Ztiles[(size_t)bi * NB * NB + r * NB + c] : 0.0;
-    }
-    // operands of this block's update, one column c per thread (rows jb..jb+nb-1 of L)
-    double lcol[NB];
-    const int cc = tid;  // D <= 1024 * k handled by the strided loop below for cc >= 1024
+  if (blockIdx.x > 0) {
+    const int c = (blockIdx.x - 1) * 256 + tid;
+    if (c < jS) {
+      const double *col = M + (size_t)jE * ld + c;
+      double s0 = 0.0, s1 = 0.0;
+      int r = 0;
+      for (; r + 16 <= np; r += 16) {
+        double v[16];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) lcol[r] = (cc < jb && r < nb) ? M[(size_t)(jb + r) * ld + cc] : 0.0;
+        for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(r + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          s0 += v[u] * xp[r + u];
+          s1 += v[u + 1] * xp[r + u + 1];
+        }
+      }
+      for (; r < np; ++r) s0 += col[(size_t)r * ld] * xp[r];
+      y[c] -= s0 + s1;
+    }
+    return;
+  }
+  const int ns = jE - jS;
+  {
+    const int c = tid & (SBW - 1), h = tid >> 7;  // two threads per column, alternate rows
+    double s = 0.0;
+    if (c < ns) {
+      const double *col = M + (size_t)jE * ld + jS + c;
+#pragma unroll 8
+      for (int r = h; r < np; r += 2) s += col[(size_t)r * ld] * xp[r];
+    }
+    part[h][c] = s;
+    __syncthreads();
+    if (tid < SBW) ys[tid] = (tid < ns) ? y[jS + tid] - part[0][tid] - part[1][tid] : 0.0;
+    if (np == 0)  // first launch on the stream: clear the gauge slots before any x is scattered
+      for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
+    __syncthreads();
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
+    const int jb = jS + t * NB, nb = min(NB, jE - jb);
+    for (int q = tid; q < NB * NB; q += blockDim.x) {
+      const int r = q / NB, c = q % NB;
+      T[r][c] = (r < nb && c >= r && c < nb) ? Ztiles[(size_t)(jb / NB) * NB * NB + q] : 0.0;
+    }
+    // operands of this tile's update inside the super-block, one column per thread
+    double lcol[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) lcol[r] = (tid < t * NB && r < nb) ? M[(size_t)(jb + r) * ld + jS + tid] : 0.0;
     __syncthreads();
     if (wave == 0) {
       const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int q = 0; q < NB / 2; q += 2) {
-        s0 += T[r][16 * h + q] * y[jb + 16 * h + q];
-        s1 += T[r][16 * h + q + 1] * y[jb + 16 * h + q + 1];
+        s0 += T[r][16 * h + q] * ys[t * NB + 16 * h + q];
+        s1 += T[r][16 * h + q + 1] * ys[t * NB + 16 * h + q + 1];
       }
       double xr = s0 + s1;
       xr += __shfl_xor(xr, 32, 64);
-      if (lane < nb) y[jb + lane] = xr;  // all reads of y above precede this write (one wave, in order)
+      if (lane < nb) ys[t * NB + lane] = xr;  // all reads of ys above precede this write (one wave, in order)
     }
     __syncthreads();
-    if (cc < jb) {
+    if (tid < t * NB) {
       double sacc = 0.0;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) sacc += lcol[r] * y[jb + r];  // y[jb + r] = 0-weighted beyond nb via lcol = 0
-      y[cc] -= sacc;
-    }
-    for (int c2 = tid + blockDim.x; c2 < jb; c2 += blockDim.x) {  // D > 1024
-      double sacc = 0.0;
-      for (int r = 0; r < nb; ++r) sacc += M[(size_t)(jb + r) * ld + c2] * y[jb + r];
-      y[c2] -= sacc;
+      for (int r = 0; r < NB; ++r) sacc += lcol[r] * ys[t * NB + r];  // lcol = 0 beyond nb
+      ys[tid] -= sacc;
     }
     __syncthreads();
   }
-  for (int i = tid; i < D; i += blockDim.x) dxi_full[keep_index(i, gauge_axis)] = y[i];
+  if (tid < ns) {
+    y[jS + tid] = ys[tid];
+    dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
+  }
 }
 
 // ---- fallback: LU with partial pivoting (what np.linalg.solve / LAPACK gesv does, ref :146) ----
@@ -1156,7 +1209,6 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((h->D + NB) * sizeof(double))));
 #undef TRY
 #undef TRYH
   *out = h;
@@ -1290,8 +1342,12 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
         hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), (D + NB) * sizeof(double), h->stream, h->d_Ared, ld, D, m,
-                       h->gauge_axis, h->d_Ztiles, h->d_dxi);
+    for (int jS = ((D - 1) / SBW) * SBW; jS >= 0; jS -= SBW) {
+      const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
+      const int nwg = (jE == D) ? 1 : 1 + (jS + 255) / 256;
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(nwg), dim3(256), 0, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles,
+                         h->d_dxi, jS, jE, jE2);
+    }
   }
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
