@@ -127,8 +127,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MVBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, communicator inside
+    # libmvba, all-reduce per solve) even at world size 1 -- the rehearsal a one-GPU box allows.
+    multi = world > 1 or os.environ.get("MVBA_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lib import _distributed, _mvba
@@ -140,11 +146,11 @@ def main():
     ba = BundleAdjuster.from_observations(sc.n_points, args.cams, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                           sc.init_R, sc.init_t, axis=sc.axis, device=local_rank)
     eng = ba._engine
-    if world > 1:
+    if multi:
         _distributed.attach_rccl(eng)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +170,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -215,7 +221,7 @@ def main():
             if args.svd_rows > 0:
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
