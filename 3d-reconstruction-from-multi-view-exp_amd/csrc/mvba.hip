@@ -448,130 +448,204 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
   return live ? *reinterpret_cast<const mvba_d4 *>(p) : mvba_d4{0.0, 0.0, 0.0, 0.0};
 }
 
-// Left-looking update of one panel workgroup with G16 16-column groups of earlier panels.
-// All loads are issued before the first MFMA: one memory latency per panel.
-template <int G16>
-__device__ __forceinline__ void panel_update(const double *pa, const double *p0, const double *p1, bool liveA, bool live0,
-                                             bool live1, int wave, mvba_d4 &accO0, mvba_d4 &accO1, mvba_d4 &accD) {
-  mvba_d4 a[G16], b0[G16], b1[G16];
-#pragma unroll
-  for (int g = 0; g < G16; ++g) {
-    a[g] = load_k4(pa + 16 * g, liveA);
-    b0[g] = load_k4(p0 + 16 * g, live0);
-    b1[g] = load_k4(p1 + 16 * g, live1);
-  }
-#pragma unroll
-  for (int g = 0; g < G16; ++g)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      accO0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][u], b0[g][u], accO0, 0, 0, 0);
-      accO1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][u], b1[g][u], accO1, 0, 0, 0);
-      if (wave < 3)
-        accD = __builtin_amdgcn_mfma_f64_16x16x4f64(wave == 0 ? b0[g][u] : b1[g][u], wave == 2 ? b1[g][u] : b0[g][u], accD, 0, 0, 0);
-    }
-}
+// One launch per 128-column super-block [jS, jE).  Workgroup = 4 waves = 64 rows below the
+// super-block (wave w: rows 16w..16w+15); EVERY workgroup also factors the whole 128x128
+// diagonal block in LDS (redundant but off the critical path of nobody: no inter-workgroup
+// dependency inside the super-block, so its four panels need one dispatch instead of four).
+// Per 32-column panel q:
+//   own rows   left-looking in registers: P_q -= sum_{q'<q} X_q' L[q][q']^T (MFMA, A operands kept
+//              in registers, B from the LDS tiles), then X_q = P_q L_qq^-T (MFMA) -> global
+//   tile (q,q) wave 0: lanes 0..31 keep row r of the tile in registers, lanes 32..63 row r of the
+//              IDENTITY: the column operations of the factorisation (entries of L broadcast with
+//              v_readlane: no LDS, every index static) turn the identity rows into L^-T (Zt)
+//   in-block   tiles (r,q), r > q: X = T L_qq^-T (MFMA, in place); then right-looking update of
+//              the remaining tiles (r,c), q < c <= r, in 16x16 sub-tiles spread over the waves
+// Workgroup 0 also writes the in-block X tiles (Lblk: this super-block's 128x128 row-major block)
+// and the L^-T tiles (Ztiles) for the back-substitution to their OWN buffers: the diagonal block
+// of M is never written, because other workgroups may still be loading it.
+// MFMA layouts: A/B lane l holds X[idx = l & 15][k = 16 g + 4 (l >> 4) + u] at step (g, u)
+// (the k-permutation of load_k4); C/D: col = l & 15, row = (l >> 4) + 4 reg.
+constexpr int TS = NB + 1;                                // padded LDS tile row stride
+constexpr int SUPER_LDS = (11 * NB * TS + 64 * TS) * 8;   // 10 tiles + Zt + Pt, bytes
+__device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
-// Workgroup = 4 waves = 64 rows below the tile (wave w: rows 16w..16w+15).
-//  A. left-looking update with the super-block's earlier columns [jS, j0): own rows x tile rows
-//     (two 16x16 MFMA tiles per wave) and the tile itself (its three lower 16x16 tiles on
-//     waves 0..2); results go to LDS (Pt, Td).
-//  B. wave 0: lanes 0..31 keep row r of the tile in registers, lanes 32..63 row r of the
-//     IDENTITY: the column operations of the factorisation (entries of L broadcast with
-//     v_readlane: no LDS, every index static) turn the identity rows into L^-T  -> LDS (Zt).
-//  C. rows below: X = P L^-T as MFMA products instead of a 496-deep substitution chain.
-// Every workgroup re-factors the tile (cheap) so the panel needs one launch.  The tile in M
-// is left untouched (other workgroups may still be reading it); what the back-substitution
-// needs is L^-T of the tile, which goes to its own buffer (Ztile).
-// MFMA operand layouts: A/B lane l holds X[idx = l & 15][k = 4 t + (l >> 4)];
-// C/D: col = l & 15, row = (l >> 4) + 4 reg.
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ M, int ld, int D, int jS, int j0, int nb,
-                                                    double *__restrict__ Ztile, int *__restrict__ flag) {
-  __shared__ double Td[NB][NB + 1];  // updated diagonal tile (lower triangle + identity padding)
-  __shared__ double Zt[NB][NB + 1];  // Zt[k][c] = (L^-T)[k][c], upper triangular
-  __shared__ double Pt[64][NB + 1];  // updated rows below the tile
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void k_chol_super(double *__restrict__ M, int ld, int D, int jS,
+                                                    double *__restrict__ Ztiles, double *__restrict__ Lblk,
+                                                    int *__restrict__ flag) {
+  extern __shared__ double lds[];
+  double (*T)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);
+  double (*Zt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 10 * NB * TS);
+  double (*Pt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 11 * NB * TS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int rowbase = j0 + nb + blockIdx.x * 64 + 16 * wave;
+  const int nbS = min(SBW, D - jS), jE = jS + nbS, nq = (nbS + NB - 1) / NB;
+  const int R0 = jE + blockIdx.x * 64 + 16 * wave;  // this wave's first row below the super-block
+  const bool wg0 = blockIdx.x == 0;
   const mvba_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  // ---- A
-  {
-    mvba_d4 accO0 = zero4, accO1 = zero4, accD = zero4;
-    const int rowA = rowbase + li;
-    const bool liveA = rowA <= D, live0 = li < nb, live1 = 16 + li < nb;
-    const double *pa = M + (size_t)min(rowA, D) * ld + jS + 4 * lk;
-    const double *p0 = M + (size_t)(j0 + (live0 ? li : 0)) * ld + jS + 4 * lk;
-    const double *p1 = M + (size_t)(j0 + (live1 ? 16 + li : 0)) * ld + jS + 4 * lk;
-    switch ((j0 - jS) / NB) {
-      case 1: panel_update<2>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
-      case 2: panel_update<4>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
-      case 3: panel_update<6>(pa, p0, p1, liveA, live0, live1, wave, accO0, accO1, accD); break;
-      default: break;
+  // own rows of all four panels, C/D layout (issued first: consumed panel by panel)
+  double P[4][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = R0 + lk + 4 * qq;
+      const double *src = M + (size_t)min(row, D) * ld + jS + NB * q;
+      P[q][qq][0] = (row <= D && NB * q + li < nbS) ? src[li] : 0.0;
+      P[q][qq][1] = (row <= D && NB * q + 16 + li < nbS) ? src[16 + li] : 0.0;
     }
+  // diagonal block -> LDS tiles (lower block triangle; identity padding beyond nbS)
+  for (int r = 0; r < nq; ++r)
+    for (int c = 0; c <= r; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rl = lk + 4 * q, row = rowbase + rl;
-      const double *src = M + (size_t)min(row, D) * ld + j0;
-      Pt[16 * wave + rl][li] = (row <= D && li < nb) ? src[li] - accO0[q] : 0.0;
-      Pt[16 * wave + rl][16 + li] = (row <= D && 16 + li < nb) ? src[16 + li] - accO1[q] : 0.0;
-      // diagonal tile: waves 0, 1, 2 hold tiles (0,0), (1,0), (1,1); wave 3 clears (0,1)
-      const int r = ((wave == 1 || wave == 2) ? 16 : 0) + rl, c = ((wave >= 2) ? 16 : 0) + li;
-      double v = (r == c) ? 1.0 : 0.0;  // identity padding beyond nb
-      if (wave < 3 && r < nb && c < nb && c <= r) v = M[(size_t)(j0 + r) * ld + j0 + c] - accD[q];
-      Td[r][c] = v;
-    }
-  }
-  __syncthreads();
-  // ---- B
-  if (wave == 0) {
-    const int r = lane & 31;
-    const bool ident = lane >= 32;
-    double a[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : Td[r][c];
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const double piv = readlane_d(a[k], k);
-      bad |= !(piv > 0.0);
-      // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
-      // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
-      double y = __builtin_amdgcn_rsq(piv);
-      y = y * (1.5 - 0.5 * piv * y * y);
-      y = y * (1.5 - 0.5 * piv * y * y);
-      a[k] = (lane == k) ? piv * y : a[k] * y;
-      // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
-#pragma unroll
-      for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
-    }
-    if (bad && blockIdx.x == 0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-    if (ident) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
-      if (blockIdx.x == 0 && r < nb) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-          if (c >= r && c < nb) Ztile[r * NB + c] = a[c];
+      for (int pass = 0; pass < 4; ++pass) {
+        const int i = (tid >> 5) + 8 * pass, j = tid & 31, gi = NB * r + i, gj = NB * c + j;
+        double v = (gi == gj) ? 1.0 : 0.0;
+        if (gi < nbS && gj <= gi) v = M[(size_t)(jS + gi) * ld + jS + gj];
+        T[tix(r, c)][i][j] = v;
       }
-    }
-  }
-  __syncthreads();
-  // ---- C: X = P Zt for this wave's 16 rows.  Zt[k][c] = 0 for k > c: the left column tile
-  // needs only t < 4.
-  if (rowbase > D) return;
-  mvba_d4 acc0 = zero4, acc1 = zero4;
+  mvba_d4 XA[3][2];  // own rows' X of the earlier panels, A layout
 #pragma unroll
-  for (int t = 0; t < NB / 4; ++t) {
-    const double av = Pt[16 * wave + li][4 * t + lk];
-    if (t < NB / 8) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[4 * t + lk][li], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[4 * t + lk][16 + li], acc1, 0, 0, 0);
-  }
+  for (int q = 0; q < 3; ++q) XA[q][0] = XA[q][1] = zero4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int row = rowbase + lk + 4 * q;
-    if (row <= D) {
-      double *dst = M + (size_t)row * ld + j0;
-      if (li < nb) dst[li] = acc0[q];
-      if (16 + li < nb) dst[16 + li] = acc1[q];
+    if (q >= nq) break;  // uniform
+    // ---- own rows: left-looking update, result to this wave's slice of Pt
+    {
+      mvba_d4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+      for (int qp = 0; qp < q; ++qp)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = 16 * g + 4 * lk + u;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(XA[qp][g][u], T[tix(q, qp)][li][k], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(XA[qp][g][u], T[tix(q, qp)][16 + li][k], acc1, 0, 0, 0);
+          }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        Pt[16 * wave + lk + 4 * qq][li] = P[q][qq][0] - acc0[qq];
+        Pt[16 * wave + lk + 4 * qq][16 + li] = P[q][qq][1] - acc1[qq];
+      }
+    }
+    __syncthreads();  // tile (q,q) final (loads / previous panel's update), Pt written
+    // ---- factor tile (q,q)
+    if (wave == 0) {
+      const int r = lane & 31;
+      const bool ident = lane >= 32;
+      double a[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : T[tix(q, q)][r][c];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double piv = readlane_d(a[k], k);
+        bad |= !(piv > 0.0);
+        // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
+        // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
+        double y = __builtin_amdgcn_rsq(piv);
+        y = y * (1.5 - 0.5 * piv * y * y);
+        y = y * (1.5 - 0.5 * piv * y * y);
+        a[k] = (lane == k) ? piv * y : a[k] * y;
+        // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
+#pragma unroll
+        for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
+      }
+      if (bad && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+      if (ident) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
+        if (wg0 && NB * q + r < nbS) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c)
+            if (c >= r && NB * q + c < nbS) Ztiles[(size_t)q * NB * NB + r * NB + c] = a[c];
+        }
+      }
+    }
+    __syncthreads();  // Zt ready
+    // ---- own rows: X = P Zt (Zt[k][c] = 0 for k > c: the left column tile needs only g = 0)
+    {
+      mvba_d4 x0 = zero4, x1 = zero4;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 16 * g + 4 * lk + u;
+          const double av = Pt[16 * wave + li][k];
+          if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[k][li], x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[k][16 + li], x1, 0, 0, 0);
+        }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = R0 + lk + 4 * qq;
+        if (row <= D) {
+          double *dst = M + (size_t)row * ld + jS + NB * q;
+          if (NB * q + li < nbS) dst[li] = x0[qq];
+          if (NB * q + 16 + li < nbS) dst[16 + li] = x1[qq];
+        }
+        if (q < 3) {
+          Pt[16 * wave + lk + 4 * qq][li] = x0[qq];
+          Pt[16 * wave + lk + 4 * qq][16 + li] = x1[qq];
+        }
+      }
+      if (q < 3) {  // C/D -> A layout through this wave's slice of Pt
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) XA[q][g][u] = Pt[16 * wave + li][16 * g + 4 * lk + u];
+      }
+    }
+    // ---- in-block tiles (r,q): X = T Zt in place, one 16-row unit per wave at a time
+    for (int e = wave; e < 2 * (nq - 1 - q); e += 4) {
+      const int r = q + 1 + (e >> 1), h = e & 1;
+      double (*tile)[TS] = T[tix(r, q)];
+      double av[2][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[g][u] = tile[16 * h + li][16 * g + 4 * lk + u];
+      mvba_d4 x0 = zero4, x1 = zero4;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 16 * g + 4 * lk + u;
+          if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Zt[k][li], x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Zt[k][16 + li], x1, 0, 0, 0);
+        }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = 16 * h + lk + 4 * qq;
+        tile[i][li] = x0[qq];
+        tile[i][16 + li] = x1[qq];
+        if (wg0 && NB * r + i < nbS) {  // columns of panel q are all < nbS here (q < r)
+          double *dst = Lblk + (size_t)(NB * r + i) * SBW + NB * q;
+          dst[li] = x0[qq];
+          dst[16 + li] = x1[qq];
+        }
+      }
+    }
+    __syncthreads();  // X tiles of panel q complete
+    // ---- in-block right-looking update: T[r][c] -= X[r][q] X[c][q]^T, q < c <= r
+    {
+      int sidx = 0;
+      for (int r = q + 1; r < nq; ++r)
+        for (int c = q + 1; c <= r; ++c)
+          for (int sub = 0; sub < 4; ++sub) {
+            const int ih = sub >> 1, jh = sub & 1;
+            if (r == c && jh > ih) continue;  // upper sub-tile of a diagonal tile: never read
+            if ((sidx++ & 3) != wave) continue;
+            mvba_d4 acc = zero4;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int k = 16 * g + 4 * lk + u;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[tix(r, q)][16 * ih + li][k], T[tix(c, q)][16 * jh + li][k], acc, 0, 0, 0);
+              }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) T[tix(r, c)][16 * ih + lk + 4 * qq][16 * jh + li] -= acc[qq];
+          }
     }
   }
 }
@@ -637,13 +711,14 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 // [jE, jE2):
 //   workgroups >= 1   y[c] -= sum_r L[r][c] x[r]  (r in [jE, jE2)) for the columns c < jS, one column
 //                     per thread, rows read coalesced: the bulk of the memory traffic, chip-wide
-//   workgroup 0       the same for its own columns [jS, jE), then the four tiles from the top:
+//   workgroup 0       the same for its own columns [jS, jE), then the four tiles from the top (in-block
+//                     L from Lblk, see k_chol_super):
 //                     x_t = (L^-T tile) y_t is a 32x32 mat-vec (tiles from k_chol_panel: no serial
 //                     substitution) and y -= L[tile rows][cols left of it in the super-block]^T x_t;
 //                     scatters x into the full 9m vector (zeros at the gauge slots).
 __global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, int ld, int D, int m, int gauge_axis,
-                                                        const double *__restrict__ Ztiles, double *__restrict__ dxi_full,
-                                                        int jS, int jE, int jE2) {
+                                                        const double *__restrict__ Ztiles, const double *__restrict__ Lblk,
+                                                        double *__restrict__ dxi_full, int jS, int jE, int jE2) {
   __shared__ double xp[SBW];  // x of the super-block above
   __shared__ double ys[SBW];  // y, then x, of this super-block
   __shared__ double part[2][SBW];
@@ -700,7 +775,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, 
     // operands of this tile's update inside the super-block, one column per thread
     double lcol[NB];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) lcol[r] = (tid < t * NB && r < nb) ? M[(size_t)(jb + r) * ld + jS + tid] : 0.0;
+    for (int r = 0; r < NB; ++r) lcol[r] = (tid < t * NB && r < nb) ? Lblk[(size_t)(t * NB + r) * SBW + tid] : 0.0;
     __syncthreads();
     if (wave == 0) {
       const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
@@ -949,7 +1024,7 @@ struct mvba_handle {
   double2 *d_rec = nullptr;  // [n_obs][8] double2: one 128-B line per observation
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
-  double *d_Ab = nullptr, *d_Ared = nullptr, *d_Ztiles = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
+  double *d_Ab = nullptr, *d_Ared = nullptr, *d_Ztiles = nullptr, *d_Lblk = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -1180,6 +1255,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
+  TRY(dmalloc(&h->d_Lblk, (size_t)((h->D + SBW - 1) / SBW) * SBW * SBW));
   TRY(dmalloc(&h->d_Ztiles, (size_t)((h->D + NB - 1) / NB) * NB * NB));
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
@@ -1206,6 +1282,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
@@ -1221,7 +1298,7 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
-                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_lu,
+                  h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -1331,12 +1408,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
                        h->d_Ared);
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
-      for (int j0 = jS; j0 < jE; j0 += NB) {
-        const int nb = std::min(NB, D - j0);
-        const int rows_below = D + 1 - (j0 + nb);  // includes the rhs row
-        hipLaunchKernelGGL(k_chol_panel, dim3((rows_below + 63) / 64), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, j0, nb,
-                           h->d_Ztiles + (size_t)(j0 / NB) * NB * NB, h->d_flag);
-      }
+      hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(256), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
+                         h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
         const int nt = (D + 1 - jE + 63) / 64;
         hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
@@ -1346,7 +1419,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
       const int nwg = (jE == D) ? 1 : 1 + (jS + 255) / 256;
       hipLaunchKernelGGL(k_chol_backsolve, dim3(nwg), dim3(256), 0, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles,
-                         h->d_dxi, jS, jE, jE2);
+                         h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_dxi, jS, jE, jE2);
     }
   }
   MVBA_HIP(hipGetLastError());

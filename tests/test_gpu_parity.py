@@ -130,6 +130,7 @@ def test_random_scene_one_step_and_short_run_vs_oracle(n, m, p, capsys):
     Eo = lm_loop(g, 2.0, -1.0, 5, verbose=False)
     assert ba._engine.n_solves == g.n_solves
     assert abs(np.sqrt(Eg / sc.n_obs) - np.sqrt(Eo / sc.n_obs)) < 1e-9
+    assert ba._engine.stats()["counts"]["lu_fallback"] == 0  # SPD system: the Cholesky path, never the LU rescue
 
 
 def test_config2_10k_x_20_full_visibility_vs_oracle():
@@ -144,6 +145,7 @@ def test_config2_10k_x_20_full_visibility_vs_oracle():
     Eg = lm_loop(ba._engine, 2.0, -1.0, 3, verbose=False)
     Eo = lm_loop(g, 2.0, -1.0, 3, verbose=False)
     assert ba._engine.n_solves == g.n_solves == 3
+    assert ba._engine.stats()["counts"]["lu_fallback"] == 0
     assert abs(np.sqrt(Eg / sc.n_obs) - np.sqrt(Eo / sc.n_obs)) < 1e-9
     Xg, fg, ug, tg, Rg = ba._engine.get_params()
     np.testing.assert_allclose(Xg, g.X, atol=1e-8)
@@ -176,6 +178,7 @@ def test_large_scene_properties_and_determinism():
             c /= 2.0
         X, f, u, t, R = eng.get_params()
         runs.append((costs, X, R, t))
+        assert eng.stats()["counts"]["lu_fallback"] == 0
         assert all(b <= a for a, b in zip(costs, costs[1:]))
         rmse = np.sqrt(costs[-1] / sc.n_obs)
         assert rmse < 1.6e-3  # observation noise sigma = 1e-3 per coordinate -> sqrt(2)*1e-3
@@ -274,6 +277,7 @@ def test_extreme_camera_counts_vs_oracle(n, m, p):
     dxi = np.zeros(m9); dxi[g.keep] = g.dxi_red
     np.testing.assert_allclose(eng.debug_read("dxi"), dxi, rtol=0, atol=1e-7 * np.abs(dxi).max())
     assert E1 == pytest.approx(E1o, rel=1e-7)
+    assert eng.stats()["counts"]["lu_fallback"] == 0
 
 
 def test_indefinite_reduced_system_takes_the_lu_path_like_numpy():
@@ -326,6 +330,7 @@ def test_config4_shape_500_cameras_8_virtual_shards():
     dxi = np.zeros(m9); dxi[g.keep] = g.dxi_red
     np.testing.assert_allclose(full.debug_read("dxi"), dxi, rtol=0, atol=1e-6 * np.abs(dxi).max())
     assert E1 == pytest.approx(E1o, rel=1e-6)
+    assert full.stats()["counts"]["lu_fallback"] == 0
     As = np.zeros_like(Af)
     for lo, hi in D.partition_points(sc.pt_ptr, 8):
         p, cidx, x = D.slice_observations(sc.pt_ptr, sc.cam_idx, sc.xy, lo, hi)
