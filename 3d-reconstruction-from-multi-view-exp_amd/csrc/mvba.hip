@@ -448,69 +448,185 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
   return live ? *reinterpret_cast<const mvba_d4 *>(p) : mvba_d4{0.0, 0.0, 0.0, 0.0};
 }
 
-// One launch per 128-column super-block [jS, jE).  Workgroup = 4 waves = 64 rows below the
-// super-block (wave w: rows 16w..16w+15); EVERY workgroup also factors the whole 128x128
-// diagonal block in LDS (redundant but off the critical path of nobody: no inter-workgroup
-// dependency inside the super-block, so its four panels need one dispatch instead of four).
-// Per 32-column panel q:
-//   own rows   left-looking in registers: P_q -= sum_{q'<q} X_q' L[q][q']^T (MFMA, A operands kept
-//              in registers, B from the LDS tiles), then X_q = P_q L_qq^-T (MFMA) -> global
-//   tile (q,q) wave 0: lanes 0..31 keep row r of the tile in registers, lanes 32..63 row r of the
-//              IDENTITY: the column operations of the factorisation (entries of L broadcast with
-//              v_readlane: no LDS, every index static) turn the identity rows into L^-T (Zt)
-//   in-block   tiles (r,q), r > q: X = T L_qq^-T (MFMA, in place); then right-looking update of
-//              the remaining tiles (r,c), q < c <= r, in 16x16 sub-tiles spread over the waves
+// One launch per 128-column super-block [jS, jE).  Workgroup = 5 waves: wave 0 runs the serial
+// chain (the four 32x32 tile factorisations), waves 1..4 ("workers", 16 rows each) own 64 rows
+// below the super-block and do all the MFMA work.  EVERY workgroup factors the whole 128x128
+// diagonal block in LDS (redundant, but there is no inter-workgroup dependency inside the
+// super-block, so its four panels need one dispatch instead of four).  Per 32-column panel q:
+//   F  wave 0: lanes 0..31 keep row r of tile (q,q) in registers, lanes 32..63 row r of the
+//      IDENTITY: the column operations of the factorisation (entries of L broadcast with
+//      v_readlane: no LDS, every index static) turn the identity rows into L^-T (Zt, double-buffered)
+//      workers, meanwhile: the updates of panel q-1 that the chain does not wait for
+//      (T[r][c] -= X[r][q-1] X[c][q-1]^T for every tile but (q,q)), their own rows of panel q-1
+//      (X = P L^-T -> global) and the left-looking update of their own rows for panel q
+//      (P_q -= sum_{q'<q} X_q' L[q][q']^T, A operands kept in registers)
+//   T  workers: in-block tiles (r,q), r > q: X = T L_qq^-T (in place)
+//   U  workers: tile (q+1,q+1) -= X[q+1][q] X[q+1][q]^T  -- the only update on the critical path
 // Workgroup 0 also writes the in-block X tiles (Lblk: this super-block's 128x128 row-major block)
 // and the L^-T tiles (Ztiles) for the back-substitution to their OWN buffers: the diagonal block
 // of M is never written, because other workgroups may still be loading it.
 // MFMA layouts: A/B lane l holds X[idx = l & 15][k = 16 g + 4 (l >> 4) + u] at step (g, u)
 // (the k-permutation of load_k4); C/D: col = l & 15, row = (l >> 4) + 4 reg.
-constexpr int TS = NB + 1;                                // padded LDS tile row stride
-constexpr int SUPER_LDS = (11 * NB * TS + 64 * TS) * 8;   // 10 tiles + Zt + Pt, bytes
+constexpr int TS = NB + 1;                               // padded LDS tile row stride
+constexpr int SUPER_THREADS = 320;
+constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS) * 8;  // 10 tiles + 2 Zt + Pt, bytes
 __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
-__global__ __launch_bounds__(256) void k_chol_super(double *__restrict__ M, int ld, int D, int jS,
-                                                    double *__restrict__ Ztiles, double *__restrict__ Lblk,
-                                                    int *__restrict__ flag) {
+// Tile factorisation on one wave (see F above); returns false if a pivot is not positive.
+__device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Zt)[TS], int lane, bool store,
+                                            double *__restrict__ Ztile, int nvalid) {
+  const int r = lane & 31;
+  const bool ident = lane >= 32;
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : tile[r][c];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const double piv = readlane_d(a[k], k);
+    bad |= !(piv > 0.0);
+    // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
+    // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
+    double y = __builtin_amdgcn_rsq(piv);
+    y = y * (1.5 - 0.5 * piv * y * y);
+    y = y * (1.5 - 0.5 * piv * y * y);
+    a[k] = (lane == k) ? piv * y : a[k] * y;
+    // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
+#pragma unroll
+    for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
+  }
+  if (ident) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
+    if (store && r < nvalid) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c >= r && c < nvalid) Ztile[r * NB + c] = a[c];
+    }
+  }
+  return !bad;
+}
+
+__global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict__ M, int ld, int D, int jS,
+                                                              double *__restrict__ Ztiles, double *__restrict__ Lblk,
+                                                              int *__restrict__ flag) {
   extern __shared__ double lds[];
   double (*T)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);
-  double (*Zt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 10 * NB * TS);
-  double (*Pt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 11 * NB * TS);
+  double (*Zt)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 10 * NB * TS);
+  double (*Pt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 12 * NB * TS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ww = wave - 1;  // worker index (wave 0: -1)
   const int li = lane & 15, lk = lane >> 4;
   const int nbS = min(SBW, D - jS), jE = jS + nbS, nq = (nbS + NB - 1) / NB;
-  const int R0 = jE + blockIdx.x * 64 + 16 * wave;  // this wave's first row below the super-block
+  const int R0 = jE + blockIdx.x * 64 + 16 * ww;  // this worker's first row below the super-block
   const bool wg0 = blockIdx.x == 0;
   const mvba_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  // own rows of all four panels, C/D layout (issued first: consumed panel by panel)
+  // workers: own rows of all four panels, C/D layout (issued first: consumed panel by panel)
   double P[4][4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int row = R0 + lk + 4 * qq;
-      const double *src = M + (size_t)min(row, D) * ld + jS + NB * q;
-      P[q][qq][0] = (row <= D && NB * q + li < nbS) ? src[li] : 0.0;
-      P[q][qq][1] = (row <= D && NB * q + 16 + li < nbS) ? src[16 + li] : 0.0;
+      const double *src = M + (size_t)min(max(row, 0), D) * ld + jS + NB * q;
+      P[q][qq][0] = (ww >= 0 && row <= D && NB * q + li < nbS) ? src[li] : 0.0;
+      P[q][qq][1] = (ww >= 0 && row <= D && NB * q + 16 + li < nbS) ? src[16 + li] : 0.0;
     }
-  // diagonal block -> LDS tiles (lower block triangle; identity padding beyond nbS)
-  for (int r = 0; r < nq; ++r)
-    for (int c = 0; c <= r; ++c)
+  // diagonal block -> LDS tiles (lower block triangle; identity padding beyond nbS); every load
+  // is issued before the first LDS store: one memory latency, not forty
+  {
+    constexpr int PASSES = (NB * NB + SUPER_THREADS - 1) / SUPER_THREADS;
+    double v[10][PASSES];
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int i = (tid >> 5) + 8 * pass, j = tid & 31, gi = NB * r + i, gj = NB * c + j;
-        double v = (gi == gj) ? 1.0 : 0.0;
-        if (gi < nbS && gj <= gi) v = M[(size_t)(jS + gi) * ld + jS + gj];
-        T[tix(r, c)][i][j] = v;
+    for (int t = 0; t < 10; ++t) {
+      const int r = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0, c = t - r * (r + 1) / 2;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = tid + ps * SUPER_THREADS, i = idx >> 5, j = idx & 31, gi = NB * r + i, gj = NB * c + j;
+        v[t][ps] = (gi == gj) ? 1.0 : 0.0;
+        if (idx < NB * NB && gi < nbS && gj <= gi) v[t][ps] = M[(size_t)(jS + gi) * ld + jS + gj];
       }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int idx = tid + ps * SUPER_THREADS;
+        if (idx < NB * NB) T[t][idx >> 5][idx & 31] = v[t][ps];
+      }
+  }
   mvba_d4 XA[3][2];  // own rows' X of the earlier panels, A layout
 #pragma unroll
   for (int q = 0; q < 3; ++q) XA[q][0] = XA[q][1] = zero4;
+
+  // own rows of panel q: X = P Zt (Zt[k][c] = 0 for k > c: the left column tile needs only g = 0),
+  // store, and keep X in A layout (through this worker's slice of Pt) for the later panels
+  auto own_trsm = [&](int q, mvba_d4 &xa0, mvba_d4 &xa1) {
+    const double (*Z)[TS] = Zt[q & 1];
+    mvba_d4 x0 = zero4, x1 = zero4;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 16 * g + 4 * lk + u;
+        const double av = Pt[16 * ww + li][k];
+        if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Z[k][li], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Z[k][16 + li], x1, 0, 0, 0);
+      }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = R0 + lk + 4 * qq;
+      if (row <= D) {
+        double *dst = M + (size_t)row * ld + jS + NB * q;
+        if (NB * q + li < nbS) dst[li] = x0[qq];
+        if (NB * q + 16 + li < nbS) dst[16 + li] = x1[qq];
+      }
+      Pt[16 * ww + lk + 4 * qq][li] = x0[qq];
+      Pt[16 * ww + lk + 4 * qq][16 + li] = x1[qq];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xa0[u] = Pt[16 * ww + li][4 * lk + u];
+      xa1[u] = Pt[16 * ww + li][16 + 4 * lk + u];
+    }
+  };
+  // 16x16 sub-tile (ih, jh) of T[r][c] -= X[r][q] X[c][q]^T
+  auto update_sub = [&](int r, int c, int q, int ih, int jh) {
+    mvba_d4 acc = zero4;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 16 * g + 4 * lk + u;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[tix(r, q)][16 * ih + li][k], T[tix(c, q)][16 * jh + li][k], acc, 0, 0, 0);
+      }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) T[tix(r, c)][16 * ih + lk + 4 * qq][16 * jh + li] -= acc[qq];
+  };
+
+  __syncthreads();  // tiles loaded
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (q >= nq) break;  // uniform
-    // ---- own rows: left-looking update, result to this wave's slice of Pt
-    {
+    // ---- F
+    if (wave == 0) {
+      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
+      if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+    } else {
+      if (q > 0) {
+        int sidx = 0;  // panel q-1's updates of every tile but (q,q)
+        for (int r = q; r < nq; ++r)
+          for (int c = q; c <= r; ++c) {
+            if (r == q && c == q) continue;
+            for (int sub = 0; sub < 4; ++sub) {
+              const int ih = sub >> 1, jh = sub & 1;
+              if (r == c && jh > ih) continue;  // upper sub-tile of a diagonal tile: never read
+              if ((sidx++ & 3) == ww) update_sub(r, c, q - 1, ih, jh);
+            }
+          }
+        own_trsm(q - 1, XA[q - 1][0], XA[q - 1][1]);
+      }
+      // own rows: left-looking update of panel q, result to this worker's slice of Pt
       mvba_d4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
       for (int qp = 0; qp < q; ++qp)
@@ -524,129 +640,52 @@ __global__ __launch_bounds__(256) void k_chol_super(double *__restrict__ M, int 
           }
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        Pt[16 * wave + lk + 4 * qq][li] = P[q][qq][0] - acc0[qq];
-        Pt[16 * wave + lk + 4 * qq][16 + li] = P[q][qq][1] - acc1[qq];
+        Pt[16 * ww + lk + 4 * qq][li] = P[q][qq][0] - acc0[qq];
+        Pt[16 * ww + lk + 4 * qq][16 + li] = P[q][qq][1] - acc1[qq];
       }
     }
-    __syncthreads();  // tile (q,q) final (loads / previous panel's update), Pt written
-    // ---- factor tile (q,q)
-    if (wave == 0) {
-      const int r = lane & 31;
-      const bool ident = lane >= 32;
-      double a[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : T[tix(q, q)][r][c];
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const double piv = readlane_d(a[k], k);
-        bad |= !(piv > 0.0);
-        // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
-        // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
-        double y = __builtin_amdgcn_rsq(piv);
-        y = y * (1.5 - 0.5 * piv * y * y);
-        y = y * (1.5 - 0.5 * piv * y * y);
-        a[k] = (lane == k) ? piv * y : a[k] * y;
-        // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
-#pragma unroll
-        for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
-      }
-      if (bad && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-      if (ident) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
-        if (wg0 && NB * q + r < nbS) {
-#pragma unroll
-          for (int c = 0; c < NB; ++c)
-            if (c >= r && NB * q + c < nbS) Ztiles[(size_t)q * NB * NB + r * NB + c] = a[c];
-        }
-      }
-    }
-    __syncthreads();  // Zt ready
-    // ---- own rows: X = P Zt (Zt[k][c] = 0 for k > c: the left column tile needs only g = 0)
-    {
-      mvba_d4 x0 = zero4, x1 = zero4;
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = 16 * g + 4 * lk + u;
-          const double av = Pt[16 * wave + li][k];
-          if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[k][li], x0, 0, 0, 0);
-          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Zt[k][16 + li], x1, 0, 0, 0);
-        }
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int row = R0 + lk + 4 * qq;
-        if (row <= D) {
-          double *dst = M + (size_t)row * ld + jS + NB * q;
-          if (NB * q + li < nbS) dst[li] = x0[qq];
-          if (NB * q + 16 + li < nbS) dst[16 + li] = x1[qq];
-        }
-        if (q < 3) {
-          Pt[16 * wave + lk + 4 * qq][li] = x0[qq];
-          Pt[16 * wave + lk + 4 * qq][16 + li] = x1[qq];
-        }
-      }
-      if (q < 3) {  // C/D -> A layout through this wave's slice of Pt
+    __syncthreads();  // Zt[q & 1] ready; tiles (r,q), r > q, final
+    // ---- T: in-block tiles (r,q): X = T Zt in place, one 16-row unit per worker at a time
+    if (wave > 0) {
+      const double (*Z)[TS] = Zt[q & 1];
+      for (int e = ww; e < 2 * (nq - 1 - q); e += 4) {
+        const int r = q + 1 + (e >> 1), h = e & 1;
+        double (*tile)[TS] = T[tix(r, q)];
+        double av[2][4];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) XA[q][g][u] = Pt[16 * wave + li][16 * g + 4 * lk + u];
-      }
-    }
-    // ---- in-block tiles (r,q): X = T Zt in place, one 16-row unit per wave at a time
-    for (int e = wave; e < 2 * (nq - 1 - q); e += 4) {
-      const int r = q + 1 + (e >> 1), h = e & 1;
-      double (*tile)[TS] = T[tix(r, q)];
-      double av[2][4];
+          for (int u = 0; u < 4; ++u) av[g][u] = tile[16 * h + li][16 * g + 4 * lk + u];
+        mvba_d4 x0 = zero4, x1 = zero4;
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) av[g][u] = tile[16 * h + li][16 * g + 4 * lk + u];
-      mvba_d4 x0 = zero4, x1 = zero4;
+          for (int u = 0; u < 4; ++u) {
+            const int k = 16 * g + 4 * lk + u;
+            if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Z[k][li], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Z[k][16 + li], x1, 0, 0, 0);
+          }
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = 16 * g + 4 * lk + u;
-          if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Zt[k][li], x0, 0, 0, 0);
-          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Zt[k][16 + li], x1, 0, 0, 0);
-        }
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int i = 16 * h + lk + 4 * qq;
-        tile[i][li] = x0[qq];
-        tile[i][16 + li] = x1[qq];
-        if (wg0 && NB * r + i < nbS) {  // columns of panel q are all < nbS here (q < r)
-          double *dst = Lblk + (size_t)(NB * r + i) * SBW + NB * q;
-          dst[li] = x0[qq];
-          dst[16 + li] = x1[qq];
+        for (int qq = 0; qq < 4; ++qq) {
+          const int i = 16 * h + lk + 4 * qq;
+          tile[i][li] = x0[qq];
+          tile[i][16 + li] = x1[qq];
+          if (wg0 && NB * r + i < nbS) {  // columns of panel q are all < nbS here (q < r)
+            double *dst = Lblk + (size_t)(NB * r + i) * SBW + NB * q;
+            dst[li] = x0[qq];
+            dst[16 + li] = x1[qq];
+          }
         }
       }
     }
     __syncthreads();  // X tiles of panel q complete
-    // ---- in-block right-looking update: T[r][c] -= X[r][q] X[c][q]^T, q < c <= r
-    {
-      int sidx = 0;
-      for (int r = q + 1; r < nq; ++r)
-        for (int c = q + 1; c <= r; ++c)
-          for (int sub = 0; sub < 4; ++sub) {
-            const int ih = sub >> 1, jh = sub & 1;
-            if (r == c && jh > ih) continue;  // upper sub-tile of a diagonal tile: never read
-            if ((sidx++ & 3) != wave) continue;
-            mvba_d4 acc = zero4;
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int k = 16 * g + 4 * lk + u;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T[tix(r, q)][16 * ih + li][k], T[tix(c, q)][16 * jh + li][k], acc, 0, 0, 0);
-              }
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) T[tix(r, c)][16 * ih + lk + 4 * qq][16 * jh + li] -= acc[qq];
-          }
-    }
+    // ---- U: the next diagonal tile, three 16x16 sub-tiles on three workers
+    if (q + 1 < nq && ww >= 0 && ww < 3) update_sub(q + 1, q + 1, q, ww == 0 ? 0 : 1, ww == 2 ? 1 : 0);
+    __syncthreads();  // tile (q+1,q+1) final
+  }
+  if (wave > 0) {  // own rows of the last panel
+    mvba_d4 d0, d1;
+    own_trsm(nq - 1, d0, d1);
   }
 }
 
@@ -1408,7 +1447,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
                        h->d_Ared);
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
-      hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(256), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
+      hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
                          h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
         const int nt = (D + 1 - jE + 63) / 64;
