@@ -405,14 +405,13 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
 // rows 0..D-1 and the right-hand side b as ROW D, so that factorising carries the forward
 // substitution along (row D ends up holding y = L^-1 b).  Two-level blocking: columns are
 // processed in super-blocks of SBW = 128 (four 32-column panels).
-//   k_chol_panel  workgroup = 4 waves per 64 rows below the tile.  Left-looking inside the
-//                 super-block: the tile and the rows are first updated with the super-block's
-//                 earlier panels (f64 MFMA, K <= 96); wave 0 factors the 32x32 tile in
-//                 registers (identity rows alongside give L^-T); the rows are X = P L^-T (MFMA)
+//   k_chol_super  ONE launch per super-block, workgroup per 64 rows below it; every workgroup
+//                 factors the 128x128 diagonal block in LDS (wave 0: tile factorisations in
+//                 registers, identity rows alongside give L^-T) and solves its own rows with
+//                 f64 MFMA (left-looking inside the super-block)
 //   k_chol_trail  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
-//                 everything right of the super-block (4x less read-modify-write traffic on C
-//                 than a per-panel update, and 4x fewer launches on the critical path)
-// then k_chol_backsolve does L^T x = y in one workgroup from the L^-T tiles.
+//                 everything right of the super-block
+// then k_chol_backsolve does L^T x = y per super-block from the L^-T tiles.
 constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 //                     per thread, rows read coalesced: the bulk of the memory traffic, chip-wide
 //   workgroup 0       the same for its own columns [jS, jE), then the four tiles from the top (in-block
 //                     L from Lblk, see k_chol_super):
-//                     x_t = (L^-T tile) y_t is a 32x32 mat-vec (tiles from k_chol_panel: no serial
+//                     x_t = (L^-T tile) y_t is a 32x32 mat-vec (tiles from k_chol_super: no serial
 //                     substitution) and y -= L[tile rows][cols left of it in the super-block]^T x_t;
 //                     scatters x into the full 9m vector (zeros at the gauge slots).
 __global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, int ld, int D, int m, int gauge_axis,
