@@ -968,9 +968,19 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
   double cost = 0.0;
   for (long long a = (long long)blockIdx.x * 32 + grp; a < npts; a += (long long)gridDim.x * 32) {
     const long long o0 = pt_ptr[a], o1 = pt_ptr[a + 1];
+    // everything this point needs is requested up front (point block, X, the lane's first
+    // observation for the cost pass): one memory latency per point instead of three
+    const double *pb = PB + 10 * a;
+    const double pb0 = pb[0], pb1 = pb[1], pb2 = pb[2], pb3 = pb[3], pb4 = pb[4], pb5 = pb[5], pb6 = pb[6], pb7 = pb[7],
+                 pb8 = pb[8];
+    const double Xa0 = X[3 * a], Xa1 = X[3 * a + 1], Xa2 = X[3 * a + 2];
+    const long long of = o0 + s;
+    const bool has_first = of < o1;
+    const double2 zf = has_first ? xy[of] : make_double2(0.0, 0.0);
+    const int cf = has_first ? cam_idx[of] : 0;
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    for (long long o = o0 + s; o < o1; o += 8) {
-      const double *dk = s_dxi + 9 * cam_idx[o];
+    for (long long o = of; o < o1; o += 8) {
+      const double *dk = s_dxi + 9 * ((o == of) ? cf : cam_idx[o]);
       const double2 *q = rec + o * REC;
       const double2 x0 = q[0], x1 = q[1], x2 = q[2], jf = q[3], w0 = q[4], w1 = q[5], w2 = q[6];
       // Jc dxi_k with the implied columns: (u,v) -> 1/f0, t -> -J_X
@@ -988,16 +998,16 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
       y1 += __shfl_xor(y1, msk, 8);
       y2 += __shfl_xor(y2, msk, 8);
     }
-    const double *pb = PB + 10 * a;
-    const double d0 = -(pb[0] * y0 + pb[1] * y1 + pb[2] * y2) - pb[6];
-    const double d1 = -(pb[1] * y0 + pb[3] * y1 + pb[4] * y2) - pb[7];
-    const double d2 = -(pb[2] * y0 + pb[4] * y1 + pb[5] * y2) - pb[8];
-    const double X0 = X[3 * a] + d0, X1 = X[3 * a + 1] + d1, X2 = X[3 * a + 2] + d2;
+    const double d0 = -(pb0 * y0 + pb1 * y1 + pb2 * y2) - pb6;
+    const double d1 = -(pb1 * y0 + pb3 * y1 + pb4 * y2) - pb7;
+    const double d2 = -(pb2 * y0 + pb4 * y1 + pb5 * y2) - pb8;
+    const double X0 = Xa0 + d0, X1 = Xa1 + d1, X2 = Xa2 + d2;
     if (s == 0) {
       dX[3 * a] = d0; dX[3 * a + 1] = d1; dX[3 * a + 2] = d2;
       Xt[3 * a] = X0; Xt[3 * a + 1] = X1; Xt[3 * a + 2] = X2;
     }
-    for (long long o = o0 + s; o < o1; o += 8) {
+    if (has_first) cost += obs_cost(X0, X1, X2, s_cam + cf * CAM_LDS, zf.x, zf.y, f0);
+    for (long long o = of + 8; o < o1; o += 8) {
       const double2 z = xy[o];
       cost += obs_cost(X0, X1, X2, s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
     }
