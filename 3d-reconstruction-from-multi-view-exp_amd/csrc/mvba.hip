@@ -966,8 +966,12 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
   const int s = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const double cu = 1.0 / f0;
   double cost = 0.0;
-  for (long long a = (long long)blockIdx.x * 32 + grp; a < npts; a += (long long)gridDim.x * 32) {
-    const long long o0 = pt_ptr[a], o1 = pt_ptr[a + 1];
+  const long long a_first = (long long)blockIdx.x * 32 + grp, a_step = (long long)gridDim.x * 32;
+  long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
+  if (a_first < npts) { nx0 = pt_ptr[a_first]; nx1 = pt_ptr[a_first + 1]; }
+  for (long long a = a_first; a < npts; a += a_step) {
+    const long long o0 = nx0, o1 = nx1;
+    if (a + a_step < npts) { nx0 = pt_ptr[a + a_step]; nx1 = pt_ptr[a + a_step + 1]; }
     // everything this point needs is requested up front (point block, X, the lane's first
     // observation for the cost pass): one memory latency per point instead of three
     const double *pb = PB + 10 * a;
