@@ -604,28 +604,38 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
   };
 
   __syncthreads();  // tiles loaded
+  // Role split by whole waves (both roles execute the same number of workgroup barriers per
+  // panel: F | B1 | T | B2 | U | B3).  Separate loops keep the chain's registers (a tile row)
+  // and the workers' registers (own rows, A operands) out of each other's live ranges.
+  if (wave == 0) {
+    for (int q = 0; q < nq; ++q) {
+      // ---- F
+      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
+      if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+      __syncthreads();  // B1: Zt[q & 1] ready; tiles (r,q), r > q, final
+      __syncthreads();  // B2: X tiles of panel q complete
+      __syncthreads();  // B3: tile (q+1,q+1) final
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (q >= nq) break;  // uniform
-    // ---- F
-    if (wave == 0) {
-      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
-      if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-    } else {
-      if (q > 0) {
-        int sidx = 0;  // panel q-1's updates of every tile but (q,q)
-        for (int r = q; r < nq; ++r)
-          for (int c = q; c <= r; ++c) {
-            if (r == q && c == q) continue;
-            for (int sub = 0; sub < 4; ++sub) {
-              const int ih = sub >> 1, jh = sub & 1;
-              if (r == c && jh > ih) continue;  // upper sub-tile of a diagonal tile: never read
-              if ((sidx++ & 3) == ww) update_sub(r, c, q - 1, ih, jh);
-            }
+    // ---- F (while wave 0 factors tile (q,q))
+    if (q > 0) {
+      int sidx = 0;  // panel q-1's updates of every tile but (q,q)
+      for (int r = q; r < nq; ++r)
+        for (int c = q; c <= r; ++c) {
+          if (r == q && c == q) continue;
+          for (int sub = 0; sub < 4; ++sub) {
+            const int ih = sub >> 1, jh = sub & 1;
+            if (r == c && jh > ih) continue;  // upper sub-tile of a diagonal tile: never read
+            if ((sidx++ & 3) == ww) update_sub(r, c, q - 1, ih, jh);
           }
-        own_trsm(q - 1, XA[q - 1][0], XA[q - 1][1]);
-      }
-      // own rows: left-looking update of panel q, result to this worker's slice of Pt
+        }
+      own_trsm(q - 1, XA[q - 1][0], XA[q - 1][1]);
+    }
+    {  // own rows: left-looking update of panel q, result to this worker's slice of Pt
       mvba_d4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
       for (int qp = 0; qp < q; ++qp)
@@ -643,9 +653,9 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
         Pt[16 * ww + lk + 4 * qq][16 + li] = P[q][qq][1] - acc1[qq];
       }
     }
-    __syncthreads();  // Zt[q & 1] ready; tiles (r,q), r > q, final
+    __syncthreads();  // B1
     // ---- T: in-block tiles (r,q): X = T Zt in place, one 16-row unit per worker at a time
-    if (wave > 0) {
+    {
       const double (*Z)[TS] = Zt[q & 1];
       for (int e = ww; e < 2 * (nq - 1 - q); e += 4) {
         const int r = q + 1 + (e >> 1), h = e & 1;
@@ -677,12 +687,12 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
         }
       }
     }
-    __syncthreads();  // X tiles of panel q complete
+    __syncthreads();  // B2
     // ---- U: the next diagonal tile, three 16x16 sub-tiles on three workers
-    if (q + 1 < nq && ww >= 0 && ww < 3) update_sub(q + 1, q + 1, q, ww == 0 ? 0 : 1, ww == 2 ? 1 : 0);
-    __syncthreads();  // tile (q+1,q+1) final
+    if (q + 1 < nq && ww < 3) update_sub(q + 1, q + 1, q, ww == 0 ? 0 : 1, ww == 2 ? 1 : 0);
+    __syncthreads();  // B3
   }
-  if (wave > 0) {  // own rows of the last panel
+  {  // own rows of the last panel
     mvba_d4 d0, d1;
     own_trsm(nq - 1, d0, d1);
   }
