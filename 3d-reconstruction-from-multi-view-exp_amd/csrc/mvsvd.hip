@@ -49,39 +49,66 @@ __device__ __forceinline__ void gram_store_partial(const svd_d4 *acc, int npairs
   }
 }
 
-// n <= 16 * NT (NT = 1 or 2): one pass over the rows forms every tile pair (1 or 3 MFMAs per 4 rows)
+// n <= 16 * NT (NT = 1 or 2): one pass over the rows forms every tile pair (1 or 3 MFMAs per 4 rows).
+// A workgroup takes GRAM_ROWS consecutive rows per step: the rows are one contiguous byte range of
+// Wt, streamed with 16-byte loads by all 256 threads into LDS (a lane-per-element gather of the
+// MFMA operands straight from HBM ran at 1.8 TB/s), then every wave picks the operands of its
+// 32 rows out of LDS.  Rows past the end are zero-filled in LDS.
+constexpr int GRAM_ROWS = 4 * ROWS_PER_STEP;  // 128 rows per workgroup step
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, long long n_rows, int n,
                                                     double *__restrict__ partial) {
+  extern __shared__ double gram_lds_raw[];
+  T *stage = reinterpret_cast<T *>(gram_lds_raw);  // GRAM_ROWS x n, row-major like Wt
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   constexpr int NP = NT * (NT + 1) / 2;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
   svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
   int col[NT];
   bool cok[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { cok[t] = GT * t + li < n; col[t] = min(GT * t + li, n - 1); }
-  const long long stride = (long long)gridDim.y * 4 * ROWS_PER_STEP;
-  for (long long r0 = ((long long)blockIdx.y * 4 + wave) * ROWS_PER_STEP; r0 < n_rows; r0 += stride) {
-    double v[ROWS_PER_STEP / 4][NT];
+  const long long total = n_rows * n;
+  const int nvec = GRAM_ROWS * n / VEC;  // GRAM_ROWS * n is a multiple of 4
+  for (long long r0 = (long long)blockIdx.y * GRAM_ROWS; r0 < n_rows; r0 += (long long)gridDim.y * GRAM_ROWS) {
+    const long long e0 = r0 * n;  // first element of the step: 16-byte aligned (r0 is a multiple of 128)
+    constexpr int MAXV = GRAM_ROWS * 32 / VEC / 256;  // n <= 32: at most this many vectors per thread
+    vec_t xs[MAXV];
 #pragma unroll
-    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {  // all loads of the step first (clamped, branch-free)
-      const long long row = r0 + 4 * g + lk;
-      const T *wr = Wt + min(row, n_rows - 1) * n;
+    for (int u = 0; u < MAXV; ++u) {  // every load of the step is issued before the first LDS store
+      const int v = threadIdx.x + 256 * u;
+      const long long idx = e0 + (long long)v * VEC;
+      if (v < nvec && idx + VEC <= total) {
+        xs[u] = *reinterpret_cast<const vec_t *>(Wt + idx);
+      } else {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const double x = (double)wr[col[t]];
-        v[g][t] = (row < n_rows && cok[t]) ? x : 0.0;
+        for (int w = 0; w < VEC; ++w) xs[u][w] = (v < nvec && idx + w < total) ? Wt[idx + w] : (T)0;
       }
     }
 #pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int v = threadIdx.x + 256 * u;
+      if (v < nvec) *reinterpret_cast<vec_t *>(stage + (size_t)v * VEC) = xs[u];
+    }
+    __syncthreads();
+    const T *rows = stage + (size_t)(wave * ROWS_PER_STEP + lk) * n;
+#pragma unroll
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
+      double v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double x = (double)rows[(size_t)(4 * g) * n + col[t]];
+        v[t] = cok[t] ? x : 0.0;
+      }
       int q = 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[g][t], v[g][u], acc[q], 0, 0, 0);
+        for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t], v[u], acc[q], 0, 0, 0);
     }
+    __syncthreads();
   }
   gram_store_partial(acc, NP, 0, NP, partial);
 }
@@ -338,9 +365,9 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   SVD_HIP(hipMemsetAsync(dG, 0, sizeof(double) * nn, st));
   SVD_HIP(hipMemsetAsync(dsum, 0, sizeof(double) * n, st));
   if (n_tiles == 1)
-    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), 0, st, dW, n_rows, n, dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, st, dW, n_rows, n, dpart);
   else if (n_tiles == 2)
-    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), 0, st, dW, n_rows, n, dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, st, dW, n_rows, n, dpart);
   else
     hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, st, dW, n_rows, n, n_tiles, n_pairs, dpart);
   hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, std::min(chunks, 32)), dim3(256), 0, st, dpart, chunks, n, n_tiles, n_pairs, dG);
