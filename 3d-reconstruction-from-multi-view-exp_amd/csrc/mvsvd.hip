@@ -263,6 +263,98 @@ __global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ Ag, double
   }
 }
 
+// n <= 32: both matrices in LDS, 256 threads, no divides or square roots on the serial path
+// (v_rcp_f64 / v_rsq_f64 seeds + Newton steps to full precision), and the two-sided update
+// A <- J^T A J in a single pass from the old A:
+//   A'[i][j] = c_i c_j A[i][j] + c_i t_j A[i][pj] + t_i c_j A[pi][j] + t_i t_j A[pi][pj]
+// with pi = partner of index i in this step's pairing and (c_i, t_i) its rotation coefficients
+// (t = -s for the smaller index of a pair, +s for the larger; c = 1, t = 0, pi = i if unpaired).
+// Thread = (row group i0 = tid >> 5, column j = tid & 31), rows i = i0 + 8u.  Measured at n = 24:
+// 4570 cycles per step on one wave (LDS-instruction bound), ~1200 with the work on 4 waves.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  return y * (2.0 - x * y);
+}
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+
+constexpr int JW = 32, JWS = JW + 1;  // max order and padded LDS stride of the small solver
+__global__ __launch_bounds__(256) void k_jacobi_small(double *__restrict__ Ag, double *__restrict__ Vg, int n, int max_sweeps,
+                                                     double tol, int *__restrict__ sweeps_done) {
+  __shared__ double A[JW * JWS], V[JW * JWS], cc[JW], tt[JW];
+  __shared__ int pn[JW];
+  __shared__ int s_rot;
+  const int tid = threadIdx.x;
+  const int np = (n + 1) & ~1, half = np / 2;
+  for (int e = tid; e < JW * JW; e += 256) {
+    const int i = e / JW, j = e % JW;
+    A[i * JWS + j] = (i < n && j < n) ? Ag[(size_t)i * n + j] : 0.0;
+    V[i * JWS + j] = (i == j) ? 1.0 : 0.0;
+  }
+  if (tid == 0) s_rot = 0;
+  __syncthreads();
+  const int j = tid & 31, i0 = tid >> 5;
+  const double tol2 = tol * tol;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    for (int step = 0; step < np - 1; ++step) {
+      if (tid < JW) { cc[tid] = 1.0; tt[tid] = 0.0; pn[tid] = tid; }
+      __syncthreads();
+      if (tid < half) {  // round-robin pairing (same schedule as k_jacobi)
+        int a, b;
+        if (tid == 0) { a = np - 1; b = step; }
+        else { a = (step + tid) % (np - 1); b = (step - tid + np - 1) % (np - 1); }
+        const int p = min(a, b), q = max(a, b);
+        if (q < n) {
+          const double apq = A[p * JWS + q], app = A[p * JWS + p], aqq = A[q * JWS + q];
+          if (apq * apq > tol2 * fabs(app * aqq) && apq != 0.0) {
+            const double tau = (aqq - app) * rcp_nr(2.0 * apq);
+            const double w = 1.0 + tau * tau;
+            const double t = copysign(1.0, tau) * rcp_nr(fabs(tau) + w * rsqrt_nr(w));
+            const double c = rsqrt_nr(1.0 + t * t), sn = t * c;
+            cc[p] = c; tt[p] = -sn; pn[p] = q;
+            cc[q] = c; tt[q] = sn; pn[q] = p;
+            s_rot = 1;  // benign race: every writer stores 1
+          }
+        }
+      }
+      __syncthreads();
+      const int pj = pn[j];
+      const double cj = cc[j], tj = tt[j];
+      double an[4], vn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 8 * u;  // rows >= n hold zeros / identity and are left alone
+        const int pi = pn[i];
+        const double ci = cc[i], ti = tt[i];
+        an[u] = ci * (cj * A[i * JWS + j] + tj * A[i * JWS + pj]) + ti * (cj * A[pi * JWS + j] + tj * A[pi * JWS + pj]);
+        vn[u] = cj * V[i * JWS + j] + tj * V[i * JWS + pj];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 8 * u;
+        if (i < n) { A[i * JWS + j] = an[u]; V[i * JWS + j] = vn[u]; }
+      }
+      __syncthreads();
+    }
+    const int any = s_rot;
+    __syncthreads();
+    if (tid == 0) s_rot = 0;
+    if (any == 0) { ++sweep; break; }  // a whole sweep without a rotation (uniform)
+  }
+  if (tid == 0) *sweeps_done = sweep;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, jj = e % n;
+    Ag[e] = A[i * JWS + jj];
+    Vg[e] = V[i * JWS + jj];
+  }
+}
+
 // S[i][row] = sum_c Mr[c][i] (Wt[row][c] - mu[c]).  A wave takes 64 consecutive rows: the 64 x n
 // tile is contiguous in memory, so it is loaded with fully coalesced accesses into a padded LDS
 // tile (odd stride -> conflict-free column reads), then each lane reduces its own row.
@@ -379,7 +471,9 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
   hipEventRecord(ev[2], st);
   const int np = (n + 1) & ~1;
   const size_t jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
-  if (n <= 64)
+  if (n <= JW)
+    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, st, dG, dV, n, 60, 1e-15, dsw);
+  else if (n <= 64)
     hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, st, dG, dV, n, 60, 1e-15, dsw);
   else
     hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, st, dG, dV, n, 60, 1e-15, dsw);
