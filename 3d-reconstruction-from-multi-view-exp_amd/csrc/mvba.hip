@@ -145,14 +145,14 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
       c9[7] = 2.0 * (J.jx[0][1] * J.e0 + J.jx[1][1] * J.e1);
       c9[8] = 2.0 * (J.jx[0][2] * J.e0 + J.jx[1][2] * J.e1);
     }
-    __builtin_amdgcn_wave_barrier();  // wave-synchronous hand-over through LDS (in-order DS queue)
+    wave_sync();  // wave-synchronous hand-over through LDS (in-order DS queue)
 #pragma unroll
     for (int q = 0; q < REC; ++q) {
       const int ol = q * 8 + (lane >> 3), pos = lane & 7;  // local observation, stored position
       const double2 v = stage[ol * REC + pos];
       if (ol < n) rec[(wbase + ol) * REC + (pos ^ (ol & 7))] = v;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     // ---- per-point sums (wave-level segmented reduction; observations are sorted by point)
     const int a_prev = __shfl_up(a, 1, 64);
     const bool head = live && (lane == 0 || a != a_prev);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
       seg_pt[rank] = a;
     }
     if (lane == 0) seg_start[nseg] = n;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const int sl = lane / 9, comp = lane - 9 * sl;
     for (int s0 = 0; s0 < nseg; s0 += 7) {
       const int sg = s0 + sl;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
         else *dst = acc;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
   }
 }
 
@@ -468,39 +468,89 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
 // (the k-permutation of load_k4); C/D: col = l & 15, row = (l >> 4) + 4 reg.
 constexpr int TS = NB + 1;                               // padded LDS tile row stride
 constexpr int SUPER_THREADS = 320;
-constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS) * 8;  // 10 tiles + 2 Zt + Pt, bytes
+constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS + 64 * 9) * 8;  // 10 tiles + 2 Zt + Pt + panel buffer, bytes
 __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
 // Tile factorisation on one wave (see F above); returns false if a pivot is not positive.
-__device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Zt)[TS], int lane, bool store,
+// The augmented 64x32 matrix B = [tile; I] (column operations turn it into [L; L^-T]) lives in
+// MFMA C/D layout (acc[row tile][column tile]).  Per panel of 8 columns:
+//   a. the panel's columns go through LDS (Xb) into a row-per-lane register block bp[8]
+//   b. 8 elimination steps restricted to the panel: 28 v_readlane broadcasts instead of ~200
+//   c. bp back to Xb (and the L^-T rows to Zt)
+//   d. every later column at once: acc -= B[:, panel] L[cols, panel]^T as f64 MFMAs whose A and
+//      B operands are both read from Xb (B operand of column tile ct = A operand of row tile ct)
+// 112 broadcast-FMAs + 32 MFMAs instead of 496 broadcast-FMAs: ~21k -> ~10k cycles per tile.
+constexpr int XBS = 9;  // padded row stride of the 64 x 8 panel buffer
+__device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Zt)[TS], double *Xb, int lane, bool store,
                                             double *__restrict__ Ztile, int nvalid) {
-  const int r = lane & 31;
-  const bool ident = lane >= 32;
-  double a[NB];
+  const int li = lane & 15, lk = lane >> 4;
+  mvba_d4 acc[4][2];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = ident ? ((r == c) ? 1.0 : 0.0) : tile[r][c];
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * (rt & 1) + lk + 4 * q, col = 16 * ct + li;
+        acc[rt][ct][q] = (rt < 2) ? tile[row][col] : ((row == col) ? 1.0 : 0.0);
+      }
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const double piv = readlane_d(a[k], k);
-    bad |= !(piv > 0.0);
-    // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
-    // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per panel
-    double y = __builtin_amdgcn_rsq(piv);
-    y = y * (1.5 - 0.5 * piv * y * y);
-    y = y * (1.5 - 0.5 * piv * y * y);
-    a[k] = (lane == k) ? piv * y : a[k] * y;
-    // tile entries above the diagonal (c > r) hold values that are never read: no predicate needed
+  for (int p = 0; p < 4; ++p) {
+    // a. panel columns 8p .. 8p+7: C/D layout -> one row per lane
+    if ((li >> 3) == (p & 1)) {
 #pragma unroll
-    for (int c = k + 1; c < NB; ++c) a[c] -= a[k] * readlane_d(a[k], c);
-  }
-  if (ident) {
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Zt[r][c] = a[c];
-    if (store && r < nvalid) {
+        for (int q = 0; q < 4; ++q) Xb[(16 * rt + lk + 4 * q) * XBS + (li & 7)] = acc[rt][p >> 1][q];
+    }
+    wave_sync();
+    double bp[8];
 #pragma unroll
-      for (int c = 0; c < NB; ++c)
-        if (c >= r && c < nvalid) Ztile[r * NB + c] = a[c];
+    for (int j = 0; j < 8; ++j) bp[j] = Xb[lane * XBS + j];
+    // b. elimination inside the panel
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double piv = readlane_d(bp[k], 8 * p + k);
+      bad |= !(piv > 0.0);
+      // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full double precision) instead of the
+      // ~40-instruction sqrt and divide expansions, which sit on the serial path 32 times per tile
+      double y = __builtin_amdgcn_rsq(piv);
+      y = y * (1.5 - 0.5 * piv * y * y);
+      y = y * (1.5 - 0.5 * piv * y * y);
+      bp[k] = (lane == 8 * p + k) ? piv * y : bp[k] * y;
+      // entries above the diagonal (column > row) hold values that are never read: no predicate needed
+#pragma unroll
+      for (int j = k + 1; j < 8; ++j) bp[j] -= bp[k] * readlane_d(bp[k], 8 * p + j);
+    }
+    // c. finished columns back to Xb; rows 32..63 are rows of L^-T
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Xb[lane * XBS + j] = bp[j];
+    if (lane >= 32) {
+      const int r = lane - 32;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 8 * p + j;
+        Zt[r][c] = bp[j];
+        if (store && r < nvalid && c >= r && c < nvalid) Ztile[r * NB + c] = bp[j];
+      }
+    }
+    // d. all later columns: acc[rt][ct] -= B[16 rt .., panel] L[16 ct .., panel]^T
+    wave_sync();
+    if (p < 3) {
+      double xa[4][2];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xa[rt][t] = Xb[(16 * rt + li) * XBS + 4 * t + lk];
+#pragma unroll
+      for (int ct = (p == 0) ? 0 : 1; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[rt][t], xa[ct][t], acc[rt][ct], 0, 0, 0);
+      wave_sync();  // the next panel overwrites Xb
     }
   }
   return !bad;
@@ -572,6 +622,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
         if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Z[k][li], x0, 0, 0, 0);
         x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Z[k][16 + li], x1, 0, 0, 0);
       }
+    wave_sync();  // every lane has read its operands out of this slice of Pt
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int row = R0 + lk + 4 * qq;
@@ -583,6 +634,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
       Pt[16 * ww + lk + 4 * qq][li] = x0[qq];
       Pt[16 * ww + lk + 4 * qq][16 + li] = x1[qq];
     }
+    wave_sync();  // C/D layout written by some lanes, A layout read by others
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       xa0[u] = Pt[16 * ww + li][4 * lk + u];
@@ -610,7 +662,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
   if (wave == 0) {
     for (int q = 0; q < nq; ++q) {
       // ---- F
-      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
+      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lds + 12 * NB * TS + 64 * TS, lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
       if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
       __syncthreads();  // B1: Zt[q & 1] ready; tiles (r,q), r > q, final
       __syncthreads();  // B2: X tiles of panel q complete
@@ -674,6 +726,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
             if (g == 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Z[k][li], x0, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][u], Z[k][16 + li], x1, 0, 0, 0);
           }
+        wave_sync();  // in place: every lane has read its operands before any lane overwrites the unit
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const int i = 16 * h + lk + 4 * qq;

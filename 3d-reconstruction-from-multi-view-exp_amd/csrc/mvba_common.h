@@ -109,4 +109,19 @@ __host__ __device__ __forceinline__ void expand_cam(const double *in15, double f
   out19[18] = 0.0;
 }
 
+
+// Lanes of ONE wave exchanging data through LDS: the hardware executes a wave's LDS instructions
+// in order, but the compiler only reasons per thread (it may, e.g., sink loads into the arms of a
+// divergent branch, where the other lanes' stores have not happened yet).  This is the
+// wave-level equivalent of __syncthreads(): a convergent barrier plus release/acquire fences.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#else
+__device__ inline void wave_sync() {}
+#endif
+
 }  // namespace mvba

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
       } else {
         for (int q = lane; q < rows_here * w; q += 64) tile[(q / w) * ldt + (q % w)] = Wt[(base + q / w) * n + c0 + (q % w)];
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
       if (lane < rows_here) {
         const T *tr = tile + lane * ldt;
         for (int c = 0; c < w; ++c) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
           acc[0] += x * mc[0]; acc[1] += x * mc[1]; acc[2] += x * mc[2]; acc[3] += x * mc[3];
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
     }
     if (lane < rows_here)
       for (int i = 0; i < r; ++i) S[(size_t)i * n_rows + base + lane] = (T)acc[i];
