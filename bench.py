@@ -32,6 +32,8 @@ for p in (PKG, ROOT):
 
 import numpy as np  # noqa: E402
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_k1_config3.json")
 
