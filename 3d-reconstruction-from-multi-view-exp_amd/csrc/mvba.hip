@@ -307,7 +307,9 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       double *dst = strip + (9 * (l - l_lo) + j) * 9;
       const bool diag = valid && (base + slot == 0);
       double val[9];
-      {
+      // a pass with no lane inside this block's column segment (strips cut into segments, m > 236)
+      // costs only its loads: wave-uniform skip of the arithmetic
+      if (__ballot(valid) != 0ull) {
         const double cjx = alpha * cs.x + beta_x, cjy = alpha * cs.y + beta_y;  // 4 * Jc_l[:, j]
         const double g0 = x0.x * cjx + x0.y * cjy;  // 2 * F_al[:, j]
         const double g1 = x1.x * cjx + x1.y * cjy;
