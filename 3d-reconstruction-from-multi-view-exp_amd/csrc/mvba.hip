@@ -1340,6 +1340,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (const char *ev = getenv("MVBA_SCHUR_CHUNKS")) h->nchunks = std::max(1, atoi(ev));
   const size_t lds_cap = 150 * 1024;
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
+  if (const char *ev = getenv("MVBA_SCHUR_LSEG")) h->lseg = std::max(1, std::min(h->lseg, atoi(ev)));
   h->nseg = (m + h->lseg - 1) / h->lseg;
   std::vector<long long> chunk_ptr((size_t)m * (h->nchunks + 1));
   for (int k = 0; k < m; ++k) {
