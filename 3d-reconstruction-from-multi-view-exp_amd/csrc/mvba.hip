@@ -230,9 +230,9 @@ __device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
 
 // LDS strip layout: strip[(9 (l - l_lo) + j) * 9 + i]  (i fastest) so that the nine
 // accumulations of a lane are ONE address + immediate offsets; sb (rhs) follows.
-template <bool BIG>  // BIG: record byte offsets need 64 bits (n_obs * 128 >= 4 GiB)
+template <bool BIG, bool SEG>  // BIG: record byte offsets need 64 bits (n_obs * 128 >= 4 GiB); SEG: strips cut into 2..4 column segments
 __global__ __launch_bounds__(768, 6) void k_schur_strip(
-    int m, int nchunks, int lseg, const long long *__restrict__ chunk_ptr, const int4 *__restrict__ csc,
+    int m, int nchunks, int lseg, int nsp, const long long *__restrict__ chunk_ptr, const int4 *__restrict__ csc,
     const int *__restrict__ cam_idx, const double2 *__restrict__ rec, const double *__restrict__ PB, double c,
     double f0, double *__restrict__ Afull, double *__restrict__ bfull) {
   extern __shared__ double strip[];
@@ -265,7 +265,12 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
   const auto *rec_c = as_const(reinterpret_cast<const double *>(rec));
   const auto *PBc = as_const(PB);
   const char *recb = reinterpret_cast<const char *>(rec);
-  auto load_rec = [&](long long i) { return make_int4(csc_c[4 * i], csc_c[4 * i + 1], csc_c[4 * i + 2], 0); };
+  auto load_rec = [&](long long i) { return make_int4(csc_c[4 * i], csc_c[4 * i + 1], csc_c[4 * i + 2], SEG ? csc_c[4 * i + 3] : 0); };
+  // SEG (strips cut into nsp = 2..4 column segments; more segments fall back to scanning): the remaining
+  // observations of an entry are sorted by camera, so this block's items are the index range
+  // [first, last) of them; csc.w packs the segment boundaries (10 bits each, built on the host).
+  auto seg_first = [&](const int4 &r) { return (SEG && seg > 0) ? ((r.w >> (10 * (seg - 1))) & 1023) : 0; };
+  auto seg_last = [&](const int4 &r) { return (SEG && seg + 1 < nsp) ? ((r.w >> (10 * seg)) & 1023) : r.z; };
   auto line = [&](int ol) -> const char * {
     if (BIG) return recb + ((size_t)ol << 7);
     return recb + ((unsigned)ol << 7);  // scalar base + 32-bit lane offset
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
   if (idx < end) {
     int4 cur = load_rec(idx);
     int4 nxt = (idx + nw < end) ? load_rec(idx + nw) : cur;
-    int base = 0;
+    int base = seg_first(cur), last = seg_last(cur);
     // k-side: ONE record line + the point block, wave-uniform scalar loads
     const double MVBA_CONST_AS *qk = rec_c + (size_t)cur.x * (2 * REC);
     const double MVBA_CONST_AS *pb = PBc + 10 * (size_t)cur.y;
@@ -292,8 +297,8 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
     const double *PBg = PB;
     // l-side of the first pass
-    bool act = slot < cur.z;
-    int ol = cur.x + (act ? slot : 0);
+    bool act = base + slot < last;
+    int ol = cur.x + (act ? base + slot : 0);
     int l = cam_idx[ol];
     const char *ql = line(ol);
     double2 x0 = *reinterpret_cast<const double2 *>(ql), x1 = *reinterpret_cast<const double2 *>(ql + 16),
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       }
       // ---------------- advance to pass n+1 and issue its loads
       bool done = false;
-      if (base + 7 < cur.z) {
+      if (base + 7 < last) {
         base += 7;
       } else {
         idx += nw;
@@ -354,7 +359,8 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           done = true;
         } else {
           cur = nxt;
-          base = 0;
+          base = seg_first(cur);
+          last = seg_last(cur);
           if (idx + nw < end) nxt = load_rec(idx + nw);
           qk = rec_c + (size_t)cur.x * (2 * REC);
           pb = PBc + 10 * (size_t)cur.y;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       }
       if (!done) {
         const int it = base + slot;
-        act = it < cur.z;
+        act = it < last;
         ol = cur.x + (act ? it : 0);
         l = cam_idx[ol];
         ql = line(ol);
@@ -1121,7 +1127,7 @@ struct mvba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   long long N = 0, nobs = 0;
-  int m = 0, gauge_axis = 0, D = 0, ld = 0;
+  int m = 0, gauge_axis = 0, D = 0, ld = 0, nsp = 0;
   double f0 = 1.0;
   // topology
   long long *d_pt_ptr = nullptr;
@@ -1342,6 +1348,16 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
   if (const char *ev = getenv("MVBA_SCHUR_LSEG")) h->lseg = std::max(1, std::min(h->lseg, atoi(ev)));
   h->nseg = (m + h->lseg - 1) / h->lseg;
+  h->nsp = (h->nseg >= 2 && h->nseg <= 4 && m < 1024) ? h->nseg : 0;
+  if (h->nsp) {  // segment boundaries inside each entry's remaining (camera-sorted) observations
+    for (long long e = 0; e < nobs; ++e) {
+      const int *cb = p->cam_idx + csc[e].x, *ce = cb + csc[e].z;
+      int w = 0;
+      for (int sgi = 1; sgi < h->nsp; ++sgi)
+        w |= (int)(std::lower_bound(cb, ce, *cb + sgi * h->lseg) - cb) << (10 * (sgi - 1));
+      csc[e].w = w;
+    }
+  }
   std::vector<long long> chunk_ptr((size_t)m * (h->nchunks + 1));
   for (int k = 0; k < m; ++k) {
     const int4 *b = csc.data() + csc_ptr[k], *e = csc.data() + csc_ptr[k + 1];
@@ -1396,8 +1412,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   // opt in to large dynamic LDS
   const int strip_lds = (int)((81 * (size_t)h->lseg + 9) * sizeof(double));
-  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
@@ -1509,8 +1527,10 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
-    auto kern = (h->nobs * 128LL >= (1LL << 32)) ? k_schur_strip<true> : k_schur_strip<false>;
-    hipLaunchKernelGGL(kern, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg,
+    const bool big = h->nobs * 128LL >= (1LL << 32);
+    auto kern = h->nsp ? (big ? k_schur_strip<true, true> : k_schur_strip<false, true>)
+                       : (big ? k_schur_strip<true, false> : k_schur_strip<false, false>);
+    hipLaunchKernelGGL(kern, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg, h->nsp,
                        h->d_chunk_ptr, h->d_csc, h->d_cam, h->d_rec, h->d_PB, c, h->f0, d_A, d_b);
   }
   MVBA_HIP(hipGetLastError());

@@ -209,6 +209,7 @@ def main():
             },
             "resid_jac_gobs_per_s": world * sc.n_obs / (k1_ms * 1e-3) / 1e9,
             "inner_solves": eng.n_solves - solves0,
+            "ms_per_inner_solve": dt / max(eng.n_solves - solves0, 1) * 1e3,
             "rmse_start": float(np.sqrt(E0 / n_obs_total)), "rmse_end": rmse,
             "roofline": {"kernel": "k_resid_jac", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(sc.n_obs),
