@@ -1527,7 +1527,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
-    const bool big = h->nobs * 128LL >= (1LL << 32);
+    const bool big = h->nobs * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");  // env: exercise the 64-bit-offset kernels at test sizes
     auto kern = h->nsp ? (big ? k_schur_strip<true, true> : k_schur_strip<false, true>)
                        : (big ? k_schur_strip<true, false> : k_schur_strip<false, false>);
     hipLaunchKernelGGL(kern, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg, h->nsp,

@@ -344,3 +344,28 @@ def test_config4_shape_500_cameras_8_virtual_shards():
         As += e.debug_read("A_full").reshape(m9, m9)
         e.close()
     np.testing.assert_allclose(As, Af, rtol=0, atol=1e-12 * np.abs(Af).max())
+
+
+@pytest.mark.parametrize("n,m,p", [(3000, 14, 0.5), (900, 300, 0.06)])
+def test_64bit_offset_schur_kernels_match_the_oracle(n, m, p, monkeypatch):
+    """The Schur kernels for more than 2^25 observations (record byte offsets beyond 4 GiB) differ
+    only in their address arithmetic; MVBA_FORCE_BIG runs them at a size the oracle can check
+    (plain and column-segmented strips)."""
+    monkeypatch.setenv("MVBA_FORCE_BIG", "1")
+    sc = make_scene(n, m, vis_p=p)
+    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                          sc.init_R, sc.init_t, axis=sc.axis)
+    g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
+    eng = ba._engine
+    eng.linearize(); g.linearize()
+    c = 1e-2
+    E1 = eng.try_step(c)
+    A, b = g.reduced_system(c)
+    E1o = g.try_step(c)
+    m9 = 9 * m
+    np.testing.assert_allclose(eng.debug_read("A_full").reshape(m9, m9), A, rtol=0, atol=1e-11 * np.abs(A).max())
+    np.testing.assert_allclose(eng.debug_read("b_full"), b, rtol=0, atol=1e-9 * np.abs(b).max())
+    assert E1 == pytest.approx(E1o, rel=1e-7)
+
