@@ -3,11 +3,12 @@
 // Replaces the numerical body of the reference's BundleAdjuster.optimize
 // (lib/bundle_adjustment.py:103-162) with a sparse, observation-list pipeline:
 //   K1  k_resid_jac      residual + 2x3 / 2x9 Jacobian rows per observation   (ref :291-427)
-//   K2  k_point_blocks   E_a = 2 sum JxT Jx, dP_a = 2 sum JxT e               (ref :429-469, :519-556)
+//   K2  (fused into K1)  E_a = 2 sum JxT Jx, dP_a = 2 sum JxT e               (ref :429-469, :519-556)
 //   K3a k_point_inv      damped 3x3 inverse, v_a = E^-1 dP_a                  (ref :120-128)
 //   K3  k_schur_strip    A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
 //   C1  ncclAllReduce    [A|b] across point shards                            
-//   K4  k_chol_* / trsv  dense solve of the gauge-reduced system              (ref :146)
+//   K4  k_chol_super / k_chol_trail / k_chol_backsolve (+ k_lu_solve rescue)
+//                        dense solve of the gauge-reduced system              (ref :146)
 //   K5+K6 k_backsub_cost dX_a, trial state, trial cost                        (ref :152-162, :260-281, :666-677)
 // HBM layout: observations sorted by point (CSR).  The linearisation of ONE
 // observation is ONE 128-byte line ("record", 8 x double2 = (row0,row1) pairs):
