@@ -369,3 +369,59 @@ def test_64bit_offset_schur_kernels_match_the_oracle(n, m, p, monkeypatch):
     np.testing.assert_allclose(eng.debug_read("b_full"), b, rtol=0, atol=1e-9 * np.abs(b).max())
     assert E1 == pytest.approx(E1o, rel=1e-7)
 
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at full size (1M points x 100 cameras x 10 %, 10M observations): too large
+    for the oracle, so size-independent properties -- the reduced systems of two point shards add
+    up to the unsharded one (linearity of the Schur accumulation across chunks and shards), the
+    cost falls monotonically to the noise floor, the gauge parameters stay put, the solver never
+    needs the LU rescue, and the residual pass agrees with an independent NumPy evaluation."""
+    from lib import _distributed as D
+
+    m = 100
+    sc = make_scene(1_000_000, m, vis_p=0.1)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    f, u = sc.init_K[:, 0, 0], sc.init_K[:, :2, 2]
+    full = _mvba.HipEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    full.set_params(X, f, u, t, R)
+    E0 = full.cost()
+    # independent cost: the oracle's vectorised residual pass (NumPy) on all 10M observations
+    pt = np.repeat(np.arange(sc.n_points), np.diff(sc.pt_ptr))
+    assert E0 == pytest.approx(O.cost(X, f, u, t, R, 1.0, pt, sc.cam_idx, sc.xy), rel=1e-10)
+    full.linearize()
+    c = 1e-4
+    E1 = full.try_step(c)
+    A, b = full.debug_read("A_full"), full.debug_read("b_full")
+    As, bs = np.zeros_like(A), np.zeros_like(b)
+    for lo, hi in D.partition_points(sc.pt_ptr, 2):
+        p, cidx, x = D.slice_observations(sc.pt_ptr, sc.cam_idx, sc.xy, lo, hi)
+        e = _mvba.HipEngine(hi - lo, m, p, cidx, x, 1.0, sc.axis)
+        e.set_params(X[lo:hi], f, u, t, R)
+        e.linearize()
+        e.try_step(c)
+        As += e.debug_read("A_full")
+        bs += e.debug_read("b_full")
+        e.close()
+    np.testing.assert_allclose(As, A, rtol=0, atol=1e-12 * np.abs(A).max())
+    np.testing.assert_allclose(bs, b, rtol=0, atol=1e-9 * np.abs(b).max())
+    assert E1 < E0
+    full.commit()
+    costs = [E0, E1]
+    for _ in range(3):
+        full.linearize()
+        c /= 2.0
+        while True:
+            E_ = full.try_step(c)
+            if E_ > costs[-1]:
+                c *= 2.0
+            else:
+                break
+        full.commit()
+        costs.append(E_)
+    assert all(b2 <= a2 for a2, b2 in zip(costs, costs[1:]))
+    assert np.sqrt(costs[-1] / sc.n_obs) < 1.35e-3  # noise sigma 1e-3 per coordinate, minus the fitted dof
+    Xn, fn, un, tn, Rn = full.get_params()
+    np.testing.assert_array_equal(tn[0], t[0])
+    np.testing.assert_array_equal(Rn[0], R[0])
+    assert full.stats()["counts"]["lu_fallback"] == 0
+
