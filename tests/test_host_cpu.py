@@ -119,3 +119,21 @@ def test_synthetic_scene_is_consistent_and_shardable():
     np.testing.assert_array_equal(part.xy, sc.xy[o0:o1])
     np.testing.assert_array_equal(part.init_X, sc.init_X[65000:68000])
     np.testing.assert_array_equal(part.pt_ptr, sc.pt_ptr[65000:68001] - o0)
+
+
+def test_bench_cpu_baseline_and_pmc_helpers():
+    """bench.py's CPU-side pieces: the oracle-timed baseline returns the contract's fields on a
+    tiny sample, and the PMC traffic helper only answers for the workload it was measured on."""
+    import json
+
+    import bench
+
+    sc = make_scene(4000, 8, vis_p=0.5)
+    cb = bench.cpu_baseline(4000, 8, 0.5, sc.n_obs, 1000)
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "it/s" and cb["value"] > 0
+    assert "1000 points" in cb["sample"]
+    d = json.load(open(bench.PMC_FILE))
+    t = bench.pmc_traffic(d["n_obs"])
+    assert t == pytest.approx((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
+    assert 0.95 < t / (152 * d["n_obs"] + 96 * d["n_points"]) < 1.10  # HBM traffic ~ algorithmic bytes
+    assert bench.pmc_traffic(d["n_obs"] + 1) is None
