@@ -1112,13 +1112,18 @@ __global__ __launch_bounds__(256) void k_cost(long long nobs, int m, const doubl
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// out[0] = cost; the status flags ride along in the next 8 bytes so that the host needs ONE
+// 16-byte device-to-host copy per trial step.
 __global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials, int n,
-                                                       double *__restrict__ out) {
+                                                       double *__restrict__ out, const int *__restrict__ flag) {
   __shared__ double s_red[16];
   double v = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
   const double t = block_sum(v, s_red);
-  if (threadIdx.x == 0) *out = t;
+  if (threadIdx.x == 0) {
+    out[0] = t;
+    reinterpret_cast<int *>(out + 1)[0] = *flag;
+  }
 }
 
 }  // namespace
@@ -1224,10 +1229,10 @@ int global_cost(mvba_handle *h, double *E) {
     ncclResult_t r = ncclAllGather(h->d_cost, h->d_allcost, 1, ncclDouble, h->comm, h->stream);
     if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
     MVBA_HIP(hipMemcpyAsync(h->h_allcost, h->d_allcost, sizeof(double) * h->nranks, hipMemcpyDeviceToHost, h->stream));
+    MVBA_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   } else {
-    MVBA_HIP(hipMemcpyAsync(h->h_cost, h->d_cost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MVBA_HIP(hipMemcpyAsync(h->h_cost, h->d_cost, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));  // cost + flags
   }
-  MVBA_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   int rc = sync_and_drain(h);
   if (rc) return rc;
   if (h->comm) {
@@ -1245,7 +1250,7 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
   hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
                      h->d_cam, h->d_xy, h->f0, h->d_partials);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag);
   MVBA_HIP(hipGetLastError());
   return MVBA_OK;
 }
@@ -1395,10 +1400,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_dxi, n9));
   TRY(dmalloc(&h->d_dX, 3 * N));
   TRY(dmalloc(&h->d_partials, h->n_partials));
-  TRY(dmalloc(&h->d_cost, 1));
+  TRY(dmalloc(&h->d_cost, 2));
   TRY(dmalloc(&h->d_flag, 1));
-  TRYH(hipHostMalloc((void **)&h->h_cost, sizeof(double)));
-  TRYH(hipHostMalloc((void **)&h->h_flag, sizeof(int)));
+  TRYH(hipHostMalloc((void **)&h->h_cost, 2 * sizeof(double)));
+  h->h_flag = reinterpret_cast<int *>(h->h_cost + 1);  // cost and flags come back in one copy
   TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
   if (nobs) {
     TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
@@ -1439,7 +1444,6 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
-  if (h->h_flag) hipHostFree(h->h_flag);
   if (h->h_allcost) hipHostFree(h->h_allcost);
   for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->pool) hipEventDestroy(e);
@@ -1574,7 +1578,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
                          h->d_xy, h->d_rec, h->d_PB, h->d_dxi, h->d_X[h->cur], h->d_cam15[trial], h->f0,
                          h->d_X[trial], h->d_dX, h->d_partials);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost, h->d_flag);
   };
   launch_tail();
   MVBA_HIP(hipGetLastError());
