@@ -186,9 +186,13 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
 
 // ------------------------------------------------------------------ K3a
 // PB[a][10] = inverse of E_a with diagonal*(1+c) (6 unique), v_a = E^-1 dP_a (3), pad.
+// Also clears the packed [A|b] the Schur kernel is about to accumulate into (one launch less on
+// the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
-                                                   double *__restrict__ PB, int *__restrict__ flag) {
+                                                   double *__restrict__ PB, int *__restrict__ flag,
+                                                   double *__restrict__ Ab, long long nAb) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = a; i < nAb; i += (long long)gridDim.x * blockDim.x) Ab[i] = 0.0;
   if (a >= npts) return;
   const double *in = PL + 9 * a;
   const double s = 1.0 + c;
@@ -1523,11 +1527,12 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   const size_t n9 = 9 * (size_t)m;
   const size_t nA = strip_offset(m, m);  // packed upper block triangle
   double *d_A = h->d_Ab, *d_b = h->d_Ab + nA;
-  MVBA_HIP(hipMemsetAsync(h->d_Ab, 0, sizeof(double) * (nA + n9), h->stream));
-  if (h->N) {
+  {
     Timed t(h, MVBA_K_POINT_INV);
-    hipLaunchKernelGGL(k_point_inv, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->N, c, h->d_PL,
-                       h->d_PB, h->d_flag);
+    const long long nAb = (long long)(nA + n9);
+    const unsigned grid = (unsigned)std::max<long long>((h->N + 255) / 256, std::min<long long>((nAb + 1023) / 1024, 4096));
+    hipLaunchKernelGGL(k_point_inv, dim3(std::max(grid, 1u)), dim3(256), 0, h->stream, h->N, c, h->d_PL, h->d_PB, h->d_flag,
+                       h->d_Ab, nAb);
   }
   if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
