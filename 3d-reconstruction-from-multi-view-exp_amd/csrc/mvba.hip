@@ -185,7 +185,9 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
 }
 
 // ------------------------------------------------------------------ K3a
-// PB[a][10] = inverse of E_a with diagonal*(1+c) (6 unique), v_a = E^-1 dP_a (3), pad.
+// PB[a][PBS] = inverse of E_a with diagonal*(1+c) (6 unique), v_a = E^-1 dP_a (3), pad: one
+// 128-byte line per point, so a gather of the inverse touches one 64-byte sector.
+constexpr int PBS = 16;
 // Also clears the packed [A|b] the Schur kernel is about to accumulate into (one launch less on
 // the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
   const double id = 1.0 / det;
   const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
   const double i11 = (xx * zz - xz * xz) * id, i12 = (xy * xz - xx * yz) * id, i22 = (xx * yy - xy * xy) * id;
-  double *out = PB + 10 * a;
+  double *out = PB + PBS * a;
   out[0] = i00; out[1] = i01; out[2] = i02; out[3] = i11; out[4] = i12; out[5] = i22;
   const double g0 = in[6], g1 = in[7], g2 = in[8];
   out[6] = i00 * g0 + i01 * g1 + i02 * g2;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     int base = seg_first(cur), last = seg_last(cur);
     // k-side: ONE record line + the point block, wave-uniform scalar loads
     const double MVBA_CONST_AS *qk = rec_c + (size_t)cur.x * (2 * REC);
-    const double MVBA_CONST_AS *pb = PBc + 10 * (size_t)cur.y;
+    const double MVBA_CONST_AS *pb = PBc + PBS * (size_t)cur.y;
     double kx00 = qk[0], kx10 = qk[1], kx01 = qk[2], kx11 = qk[3], kx02 = qk[4], kx12 = qk[5];
     double kf0 = qk[6], kf1 = qk[7];
     double kw00 = qk[8], kw10 = qk[9], kw01 = qk[10], kw11 = qk[11], kw02 = qk[12], kw12 = qk[13];
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           t0 -= d0;
           t1 -= d1;
           dacc += c * 0.125 * (cjx * cjx + cjy * cjy);  // c * 2 |Jc_k[:, j]|^2
-          const double *pv = PBg + 10 * (size_t)cur.y + 6;
+          const double *pv = PBg + PBS * (size_t)cur.y + 6;
           const double2 ke = *reinterpret_cast<const double2 *>(line(cur.x) + 112);
           const double w0 = kx00 * pv[0] + kx01 * pv[1] + kx02 * pv[2] - ke.x;
           const double w1 = kx10 * pv[0] + kx11 * pv[1] + kx12 * pv[2] - ke.y;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
           last = seg_last(cur);
           if (idx + nw < end) nxt = load_rec(idx + nw);
           qk = rec_c + (size_t)cur.x * (2 * REC);
-          pb = PBc + 10 * (size_t)cur.y;
+          pb = PBc + PBS * (size_t)cur.y;
           kx00 = qk[0]; kx10 = qk[1]; kx01 = qk[2]; kx11 = qk[3]; kx02 = qk[4]; kx12 = qk[5];
           kf0 = qk[6]; kf1 = qk[7];
           kw00 = qk[8]; kw10 = qk[9]; kw01 = qk[10]; kw11 = qk[11]; kw02 = qk[12]; kw12 = qk[13];
@@ -409,6 +411,253 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
     if (val != 0.0) atomicAdd(&Ak[(size_t)row * Wk + col], val);
   }
   if (seg == 0 && threadIdx.x < 9) atomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ K3 (pair-major form)
+// The same sum, organised by OUTPUT block instead of by camera strip.  Every (point, camera k,
+// camera l >= k) triple is an "item" (built once on the host, sorted by (k, l), then by point), a
+// "unit" is a contiguous run of one pair's items, and ONE WAVE owns a unit: it keeps its share of the
+// 9x9 block in registers for the whole run, so there is no scatter and no atomic at all -- the
+// strip kernel above spends 75 % of its cycles in the LDS atomic pipe.  Per item the block is the
+// rank-2 product  -4 Jc_k^T t Jc_l  with  t = Jx_k E^-1 Jx_l^T (2x2).
+//   lanes      lane = 3 item + cg: 21 items per step, column group cg owns columns 3cg..3cg+2 of
+//              the block (f,u,v | t | omega) = 27 accumulators; t is formed redundantly by the 3 lanes
+//   operands   whole 128-byte lines gathered by LDS-DMA (global_load_lds_dwordx4, 8 lanes -> 7 of the
+//              8 slots of a record): the k-side record, the l-side record and the point block of the
+//              21 items land in wave-private LDS as 112-byte rows (28-dword stride: the 16 lanes of a
+//              ds_read_b128 group hit 16 different bank quads).  Per-lane loads out of 64 different
+//              lines are bound by the L1 tag rate (1 line per clock: tools/microbench/gather_lines.hip,
+//              297 vs 720 lines/us/CU from L2).
+//   diagonal   a (k,k) pair adds G_k (t - I/2 instead of t), the Marquardt term c * diag(G_k) and
+//              the right-hand side 2 Jc_k^T (Jx_k E^-1 dP - e); its l-side DMA fetches slots 1..7 of
+//              the SAME record (the residual is slot 7) and the point row is 5 slots (E^-1 dP behind
+//              the inverse).  Diagonal pairs hold ~10x the items of an off-diagonal pair and are dealt
+//              round-robin into sub-lists, so that all units of a strip sweep the points at one pace.
+//   placement  the units of strip k run on XCD k % 8 (work queues per XCD, the wave reads its
+//              XCC_ID and pulls from that queue first, then steals): the ~5.5 units that need the
+//              k-side record of one observation run at the same time on the same L2.
+//   output     partial[unit][104] (81 block, 9 damping, 9 rhs), summed per pair in unit order by
+//              k_schur_reduce into the packed strips: bitwise reproducible, no zero-fill of A.
+constexpr int PSTEP = 21;                       // items per wave step
+constexpr int PROW = 7 * 16;                    // staged bytes per record (slots 0..6, or 1..7)
+constexpr int PWAVE_LDS = PSTEP * (2 * PROW + 5 * 16);  // k rows, l rows, point rows
+constexpr int UNIT_STRIDE = 104;                // doubles per unit partial
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
+}
+
+// One unit (n items from `beg`) on one wave; DIAG: the unit belongs to a (k,k) pair.
+// Two LDS buffers per wave: the DMA of step n+1 is issued before step n is computed, with indices
+// that were loaded one step earlier still (vmcnt counts in issue order, so one wait per step covers
+// both).  12 waves x 6 KB in flight per CU is what a random-line gather needs to run at the HBM
+// rate (Little: 6.4 TB/s x ~2.5 us / 256 CUs).
+// Loads and DMAs are unconditional (rows past the end of the unit are clamped to its last item and
+// land in LDS rows nobody reads): a load under a data-dependent branch makes hipcc wait vmcnt(0)
+// per load, and so does a spilled register reloaded between two DMAs -- either drains the DMAs in
+// flight.  Only lane 63 of a record DMA is masked off (9 rows x 7 slots = 63 lanes; its 16 bytes
+// would land on the next chunk's first slot).
+template <bool DIAG>
+__device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, const long long beg, const int n,
+                                                 const int *__restrict__ it_k, const int *__restrict__ it_l,
+                                                 const int *__restrict__ it_a, const double2 *__restrict__ rec,
+                                                 const double *__restrict__ PB, const double c, const double cu,
+                                                 double *__restrict__ out) {
+  constexpr int NPS = DIAG ? 5 : 3;                      // staged 16-byte slots of a point row
+  const int it = lane / 3, cg = lane - 3 * it;           // compute: item of the step, column group
+  const int drow = lane / 7, dslot = lane - 7 * drow;    // record DMA: 9 rows x 7 slots per instruction
+  const int prow = lane / NPS, pslot = lane - NPS * prow;
+  const int prow2 = (64 + lane) / 5, pslot2 = (64 + lane) - 5 * prow2;  // DIAG: second point-row DMA
+  // column q of this lane = al12 * (row slot sel_q) + unit vector; sign and 1/f0 are applied at the end
+  const int sel0 = cg == 0 ? 3 : (cg == 1 ? 0 : 4);
+  const int sel1 = cg == 0 ? 0 : sel0 + 1, sel2 = cg == 0 ? 0 : sel0 + 2;
+  const double al12 = cg == 0 ? 0.0 : 1.0, bx1 = cg == 0 ? 1.0 : 0.0;
+  double acc[9][3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[i][q] = 0.0;
+  double dg[3] = {0.0, 0.0, 0.0}, rb[3] = {0.0, 0.0, 0.0};
+
+  int ixk[3], ixl[3], ixa[2];
+  auto load_idx = [&](int s0) {  // indices of the step starting at item s0 (to registers)
+    const int last = min(PSTEP, n - s0) - 1;
+    const int *pk = it_k + beg + s0, *pl = it_l + beg + s0, *pa = it_a + beg + s0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int row = min(9 * q + drow, last);
+      ixk[q] = pk[row];
+      if (!DIAG) ixl[q] = pl[row];
+    }
+    if (DIAG) ixl[0] = pk[min(lane, last)];  // the record whose residual slot this lane fetches
+    ixa[0] = pa[min(prow, last)];
+    if (DIAG) ixa[1] = pa[min(prow2, last)];
+  };
+  auto issue = [&](char *buf) {
+    char *kb = buf, *lb = buf + PSTEP * PROW, *pb_ = lb + PSTEP * PROW;
+    if (lane < 63) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        lds_dma16(rec + (size_t)ixk[q] * REC + dslot, kb + q * (9 * PROW));
+        if (!DIAG) lds_dma16(rec + (size_t)ixl[q] * REC + dslot, lb + q * (9 * PROW));
+      }
+      if (!DIAG) lds_dma16(PB + (size_t)ixa[0] * PBS + 2 * pslot, pb_);
+    }
+    if (lane < 7 * (PSTEP - 18)) {  // third chunk: rows 18..20 only (a buffer holds 21 rows)
+      lds_dma16(rec + (size_t)ixk[2] * REC + dslot, kb + 2 * (9 * PROW));
+      if (!DIAG) lds_dma16(rec + (size_t)ixl[2] * REC + dslot, lb + 2 * (9 * PROW));
+    }
+    if (DIAG) {  // l-side == k-side: only the residual (slot 7) is fetched, 16 bytes per item
+      if (lane < PSTEP) lds_dma16(rec + (size_t)ixl[0] * REC + 7, lb);
+      lds_dma16(PB + (size_t)ixa[0] * PBS + 2 * pslot, pb_);
+      if (lane < 5 * PSTEP - 64) lds_dma16(PB + (size_t)ixa[1] * PBS + 2 * pslot2, pb_ + 1024);
+    }
+  };
+  load_idx(0);
+  issue(wbuf);
+  if (PSTEP < n) load_idx(PSTEP);
+  for (int s0 = 0, par = 0; s0 < n; s0 += PSTEP, par ^= 1) {
+    const int ns = min(PSTEP, n - s0);
+    char *kbuf = wbuf + par * PWAVE_LDS, *lbuf = kbuf + PSTEP * PROW, *pbuf = lbuf + PSTEP * PROW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's rows have landed, the next step's indices too
+    if (s0 + PSTEP < n) {
+      issue(wbuf + (par ^ 1) * PWAVE_LDS);
+      if (s0 + 2 * PSTEP < n) load_idx(s0 + 2 * PSTEP);
+    }
+    if (it < ns) {
+      const double2 *kr = reinterpret_cast<const double2 *>(kbuf + it * PROW);
+      const double2 *lr = DIAG ? kr : reinterpret_cast<const double2 *>(lbuf + it * PROW);
+      const double *pb = reinterpret_cast<const double *>(pbuf + it * (16 * NPS));
+      const double2 kx0 = kr[0], kx1 = kr[1], kx2 = kr[2], kf = kr[3], kw0 = kr[4], kw1 = kr[5], kw2 = kr[6];
+      const double2 lx0 = lr[0], lx1 = lr[1], lx2 = lr[2];
+      const double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
+      // h = E^-1 Jx_l^T (3x2), t = Jx_k h (2x2)
+      const double h0x = i00 * lx0.x + i01 * lx1.x + i02 * lx2.x, h0y = i00 * lx0.y + i01 * lx1.y + i02 * lx2.y;
+      const double h1x = i01 * lx0.x + i11 * lx1.x + i12 * lx2.x, h1y = i01 * lx0.y + i11 * lx1.y + i12 * lx2.y;
+      const double h2x = i02 * lx0.x + i12 * lx1.x + i22 * lx2.x, h2y = i02 * lx0.y + i12 * lx1.y + i22 * lx2.y;
+      double t00 = kx0.x * h0x + kx1.x * h1x + kx2.x * h2x, t01 = kx0.x * h0y + kx1.x * h1y + kx2.x * h2y;
+      double t10 = kx0.y * h0x + kx1.y * h1x + kx2.y * h2x, t11 = kx0.y * h0y + kx1.y * h1y + kx2.y * h2y;
+      double w0 = 0.0, w1 = 0.0;
+      if (DIAG) {
+        t00 -= 0.5;
+        t11 -= 0.5;
+        const double2 e = reinterpret_cast<const double2 *>(lbuf)[it];
+        w0 = kx0.x * pb[6] + kx1.x * pb[7] + kx2.x * pb[8] - e.x;
+        w1 = kx0.y * pb[6] + kx1.y * pb[7] + kx2.y * pb[8] - e.y;
+      }
+      const double2 s0v = lr[sel0], s1v = lr[sel1], s2v = lr[sel2];
+      const double sx[3] = {s0v.x, al12 * s1v.x + bx1, al12 * s2v.x};
+      const double sy[3] = {s0v.y, al12 * s1v.y, al12 * s2v.y + bx1};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double v0 = t00 * sx[q] + t01 * sy[q], v1 = t10 * sx[q] + t11 * sy[q];
+        acc[0][q] += kf.x * v0 + kf.y * v1;
+        acc[1][q] += v0;
+        acc[2][q] += v1;
+        acc[3][q] += kx0.x * v0 + kx0.y * v1;
+        acc[4][q] += kx1.x * v0 + kx1.y * v1;
+        acc[5][q] += kx2.x * v0 + kx2.y * v1;
+        acc[6][q] += kw0.x * v0 + kw0.y * v1;
+        acc[7][q] += kw1.x * v0 + kw1.y * v1;
+        acc[8][q] += kw2.x * v0 + kw2.y * v1;
+        if (DIAG) {
+          dg[q] += sx[q] * sx[q] + sy[q] * sy[q];
+          rb[q] += sx[q] * w0 + sy[q] * w1;
+        }
+      }
+    }
+    // the LDS reads above are complete (their values were consumed) before this buffer is refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // ---- sum over the 21 item lanes of each column group (fixed tree), lanes 0..2 write the partial
+  auto tree = [&](double v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      const double o = __shfl_down(v, 3 * off, 64);
+      if (it < off && it + off < PSTEP) v += o;
+    }
+    return v;
+  };
+  // J_C row i = rs_i * (record columns): f | u,v (1/f0) | t (-Jx) | omega; the same factors per column
+  const double cs0 = cg == 1 ? -1.0 : 1.0, cs12 = cg == 0 ? cu : cs0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double rs = (i == 1 || i == 2) ? cu : ((i >= 3 && i < 6) ? -1.0 : 1.0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double v = tree(acc[i][q]);
+      if (lane < 3) out[9 * i + 3 * cg + q] = -4.0 * rs * (q == 0 ? cs0 : cs12) * v;
+    }
+  }
+  if (DIAG) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double d = tree(dg[q]), r = tree(rb[q]);
+      const double cs = q == 0 ? cs0 : cs12;
+      if (lane < 3) {
+        out[81 + 3 * cg + q] = 2.0 * c * cs * cs * d;  // c * diag(G_k)   (ref :123-125)
+        out[90 + 3 * cg + q] = 2.0 * cs * r;           // 2 Jc_k^T (Jx_k E^-1 dP - e)
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
+                                                        const int *__restrict__ q_units, int *__restrict__ head,
+                                                        const int *__restrict__ it_k, const int *__restrict__ it_l,
+                                                        const int *__restrict__ it_a, const double2 *__restrict__ rec,
+                                                        const double *__restrict__ PB, double c, double f0,
+                                                        double *__restrict__ partial) {
+  extern __shared__ char smem_pairs[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  char *wbuf = smem_pairs + w * (2 * PWAVE_LDS);
+  // ---- pull one unit: own XCD's queue first, then the others (every queue entry is taken exactly
+  // once: the grid has as many waves as there are units, and a wave takes at most one)
+  int u = -1;
+  if (lane == 0) {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    for (int t = 0; t < 8 && u < 0; ++t) {
+      const int x = (xcc + t) & 7, len = q_ptr[x + 1] - q_ptr[x];
+      if (len <= 0) continue;
+      const int q = atomicAdd(&head[x], 1);
+      if (q < len) u = q_units[q_ptr[x] + q];
+    }
+  }
+  u = __builtin_amdgcn_readfirstlane(u);
+  if (u < 0) return;
+  const int4 ud = units[u];
+  const long long beg = ((long long)ud.y << 32) | (unsigned)ud.x;
+  const int n = ud.z, cam_k = (int)((unsigned)ud.w >> 16), cam_l = ud.w & 0xffff;
+  double *out = partial + (size_t)u * UNIT_STRIDE;
+  if (cam_k == cam_l) schur_pairs_unit<true>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+  else schur_pairs_unit<false>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+}
+
+// One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
+__global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restrict__ unit_ptr,
+                                                      const double *__restrict__ partial, double *__restrict__ Afull,
+                                                      double *__restrict__ bfull, int *__restrict__ head) {
+  const int k = blockIdx.x, l = k + blockIdx.y;
+  if (l >= m) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) head[threadIdx.x] = 0;  // work queues for the next launch
+  const long long p = (long long)k * m - (long long)k * (k - 1) / 2 + (l - k);
+  const int u0 = unit_ptr[p], u1 = unit_ptr[p + 1];
+  const int e = threadIdx.x;
+  if (e >= (k == l ? 99 : 81)) return;
+  double v = 0.0;
+  for (int uu = u0; uu < u1; ++uu) v += partial[(size_t)uu * UNIT_STRIDE + e];
+  double *Ak = Afull + strip_offset(k, m);
+  const int Wk = 9 * (m - k);
+  if (e < 81) {
+    const int i = e / 9, j = e - 9 * i;
+    double d = 0.0;
+    if (k == l && i == j)  // Marquardt damping of G_k's diagonal
+      for (int uu = u0; uu < u1; ++uu) d += partial[(size_t)uu * UNIT_STRIDE + 81 + i];
+    Ak[(size_t)i * Wk + 9 * (l - k) + j] = v + d;
+  } else if (e >= 90) {
+    bfull[9 * k + (e - 90)] = v;
+  }
 }
 
 // ------------------------------------------------------------------ K4: gauge strip + Cholesky
@@ -1050,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
     if (a + a_step < npts) { nx0 = pt_ptr[a + a_step]; nx1 = pt_ptr[a + a_step + 1]; }
     // everything this point needs is requested up front (point block, X, the lane's first
     // observation for the cost pass): one memory latency per point instead of three
-    const double *pb = PB + 10 * a;
+    const double *pb = PB + PBS * a;
     const double pb0 = pb[0], pb1 = pb[1], pb2 = pb[2], pb3 = pb[3], pb4 = pb[4], pb5 = pb[5], pb6 = pb[6], pb7 = pb[7],
                  pb8 = pb[8];
     const double Xa0 = X[3 * a], Xa1 = X[3 * a + 1], Xa2 = X[3 * a + 2];
@@ -1149,6 +1398,14 @@ struct mvba_handle {
   bool any_split = false;
   long long *d_chunk_ptr = nullptr;
   int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768, k1_threads = 512;
+  // pair-major Schur index (k_schur_pairs): items sorted by (k, l, point), units, per-XCD work queues
+  bool use_pairs = true;
+  long long n_items = 0, n_items_offdiag = 0;
+  int n_units = 0, rccl_version = 0;
+  int *d_it_k = nullptr, *d_it_l = nullptr, *d_it_a = nullptr, *d_unit_ptr = nullptr, *d_q_ptr = nullptr, *d_q_units = nullptr,
+      *d_q_head = nullptr;
+  int4 *d_units = nullptr;
+  double *d_partial = nullptr;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
@@ -1377,6 +1634,102 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       chunk_ptr[(size_t)k * (h->nchunks + 1) + c] = it - csc.data();
     }
   }
+
+  // ---- pair-major Schur index (see k_schur_pairs).  Items (obs of k, obs of l, point) for every
+  // pair k <= l of a point's cameras, counting-sorted by pair, ascending point inside a pair.
+  if (const char *ev = getenv("MVBA_SCHUR")) h->use_pairs = strcmp(ev, "strip") != 0;
+  if (m > 65535) h->use_pairs = false;
+  std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units;
+  std::vector<int4> units;
+  if (h->use_pairs) {
+    const long long P = (long long)m * (m + 1) / 2;
+    auto pair_id = [m](int k, int l) { return (long long)k * m - (long long)k * (k - 1) / 2 + (l - k); };
+    std::vector<long long> cnt(P, 0);
+    for (long long a = 0; a < N; ++a) {
+      const int *cb = p->cam_idx + p->pt_ptr[a];
+      const int d = (int)(p->pt_ptr[a + 1] - p->pt_ptr[a]);
+      for (int i = 0; i < d; ++i) {
+        long long *row = cnt.data() + pair_id(cb[i], cb[i]) - cb[i];  // row[l] = cnt[pair(k, l)]
+        for (int j = i; j < d; ++j) row[cb[j]]++;
+      }
+    }
+    long long T = 0, Tdiag = 0;
+    for (int k = 0; k < m; ++k) Tdiag += cnt[pair_id(k, k)];
+    for (long long q = 0; q < P; ++q) T += cnt[q];
+    if (T >= (1LL << 40)) { mvba_destroy(h); return fail(MVBA_ERR_BADARG, "too many (point, camera pair) items"); }
+    // a pair much larger than the typical off-diagonal one (the diagonal pairs: every observation of
+    // the camera) is dealt round-robin into S sub-lists that sweep the points at the common pace
+    const long long target = std::max<long long>(1, (T - Tdiag) / std::max<long long>(1, P - m));
+    long long unit_items = 1536;  // items per unit (a wave's run): ~70 steps of 21
+    if (const char *ev = getenv("MVBA_PAIR_UNIT")) unit_items = std::max(21, atoi(ev));
+    std::vector<int> S(P), vp_ptr(P + 1, 0);
+    for (long long q = 0; q < P; ++q) {
+      S[q] = (int)std::max<long long>(1, std::min<long long>(256, (cnt[q] + target / 2) / target));
+      vp_ptr[q + 1] = vp_ptr[q] + S[q];
+    }
+    const int VP = vp_ptr[P];
+    // point ranges per list: long runs for big problems, but small ones still get ~4096 units of >= 128 items
+    const long long nR_big = (target + unit_items / 2) / unit_items, nR_fill = std::min<long long>((4096 + VP - 1) / VP, target / 128);
+    const int nR = (int)std::max<long long>(1, std::min<long long>(64, std::max(nR_big, nR_fill)));
+    std::vector<long long> vp_off(VP + 1, 0);
+    for (long long q = 0; q < P; ++q)
+      for (int sI = 0; sI < S[q]; ++sI) vp_off[vp_ptr[q] + sI + 1] = (cnt[q] - sI + S[q] - 1) / S[q];
+    for (int v = 0; v < VP; ++v) vp_off[v + 1] += vp_off[v];
+    it_k.resize(T); it_l.resize(T); it_a.resize(T);
+    {
+      std::vector<long long> run(P, 0);
+      for (long long a = 0; a < N; ++a) {
+        const long long o0 = p->pt_ptr[a];
+        const int *cb = p->cam_idx + o0;
+        const int d = (int)(p->pt_ptr[a + 1] - o0);
+        for (int i = 0; i < d; ++i) {
+          const long long rowp = pair_id(cb[i], cb[i]) - cb[i];
+          for (int j = i; j < d; ++j) {
+            const long long q = rowp + cb[j], r = run[q]++;
+            const int sI = (int)(r % S[q]);
+            const long long pos = vp_off[vp_ptr[q] + sI] + r / S[q];
+            it_k[pos] = (int)(o0 + i); it_l[pos] = (int)(o0 + j); it_a[pos] = (int)a;
+          }
+        }
+      }
+    }
+    // units: (pair, sub-list, point range), numbered pair-major (k_schur_reduce sums them in this order)
+    unit_ptr.assign(P + 1, 0);
+    std::vector<int> uid((size_t)VP * nR, -1);
+    for (int k = 0; k < m; ++k)
+      for (int l = k; l < m; ++l) {
+        const long long q = pair_id(k, l);
+        unit_ptr[q] = (int)units.size();
+        for (int sI = 0; sI < S[q]; ++sI) {
+          const int v = vp_ptr[q] + sI;
+          const int *b = it_a.data() + vp_off[v], *e = it_a.data() + vp_off[v + 1];
+          for (int r = 0; r < nR; ++r) {
+            const long long a_lo = (long long)((__int128)N * r / nR), a_hi = (long long)((__int128)N * (r + 1) / nR);
+            const long long lo = std::lower_bound(b, e, a_lo) - it_a.data(), hi = std::lower_bound(b, e, a_hi) - it_a.data();
+            if (hi <= lo) continue;
+            uid[(size_t)v * nR + r] = (int)units.size();
+            units.push_back(make_int4((int)(lo & 0xffffffffLL), (int)(lo >> 32), (int)(hi - lo), (k << 16) | l));
+          }
+        }
+      }
+    unit_ptr[P] = (int)units.size();
+    // work queues: strip k on XCD k % 8, inside a queue by (k, range, l, sub-list)
+    for (int x = 0; x < 8; ++x) {
+      for (int k = x; k < m; k += 8)
+        for (int r = 0; r < nR; ++r)
+          for (int l = k; l < m; ++l) {
+            const long long q = pair_id(k, l);
+            for (int sI = 0; sI < S[q]; ++sI) {
+              const int id = uid[(size_t)(vp_ptr[q] + sI) * nR + r];
+              if (id >= 0) q_units.push_back(id);
+            }
+          }
+      q_ptr[x + 1] = (int)q_units.size();
+    }
+    h->n_items = T;
+    h->n_items_offdiag = T - Tdiag;
+    h->n_units = (int)units.size();
+  }
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
   h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks, k_backsub_cost at most 4096
 
@@ -1395,7 +1748,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
   TRY(dmalloc(&h->d_rec, (size_t)REC * nobs));
   TRY(dmalloc(&h->d_PL, 9 * N));
-  TRY(dmalloc(&h->d_PB, 10 * N));
+  TRY(dmalloc(&h->d_PB, (size_t)PBS * N));
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
@@ -1420,6 +1773,24 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(N, 1)));
   TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
+  if (h->use_pairs) {
+    const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
+    TRY(dmalloc(&h->d_it_k, it_k.size())); TRY(dmalloc(&h->d_it_l, it_l.size())); TRY(dmalloc(&h->d_it_a, it_a.size()));
+    TRY(dmalloc(&h->d_units, units.size())); TRY(dmalloc(&h->d_unit_ptr, P1));
+    TRY(dmalloc(&h->d_q_ptr, 9)); TRY(dmalloc(&h->d_q_units, q_units.size())); TRY(dmalloc(&h->d_q_head, 8));
+    TRY(dmalloc(&h->d_partial, (size_t)UNIT_STRIDE * units.size()));
+    if (!it_k.empty()) {
+      TRYH(hipMemcpy(h->d_it_k, it_k.data(), sizeof(int) * it_k.size(), hipMemcpyHostToDevice));
+      TRYH(hipMemcpy(h->d_it_l, it_l.data(), sizeof(int) * it_l.size(), hipMemcpyHostToDevice));
+      TRYH(hipMemcpy(h->d_it_a, it_a.data(), sizeof(int) * it_a.size(), hipMemcpyHostToDevice));
+      TRYH(hipMemcpy(h->d_units, units.data(), sizeof(int4) * units.size(), hipMemcpyHostToDevice));
+      TRYH(hipMemcpy(h->d_q_units, q_units.data(), sizeof(int) * q_units.size(), hipMemcpyHostToDevice));
+    }
+    TRYH(hipMemcpy(h->d_unit_ptr, unit_ptr.data(), sizeof(int) * P1, hipMemcpyHostToDevice));
+    TRYH(hipMemcpy(h->d_q_ptr, q_ptr.data(), sizeof(int) * 9, hipMemcpyHostToDevice));
+    TRYH(hipMemset(h->d_q_head, 0, sizeof(int) * 8));
+    TRYH(hipMemset(h->d_partial, 0, sizeof(double) * UNIT_STRIDE * std::max<size_t>(units.size(), 1)));
+  }
   // opt in to large dynamic LDS
   const int strip_lds = (int)((81 * (size_t)h->lseg + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
@@ -1445,7 +1816,8 @@ void mvba_destroy(mvba_handle *h) {
   if (h->comm) ncclCommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
-                  h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost};
+                  h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_allcost) hipHostFree(h->h_allcost);
@@ -1534,7 +1906,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     hipLaunchKernelGGL(k_point_inv, dim3(std::max(grid, 1u)), dim3(256), 0, h->stream, h->N, c, h->d_PL, h->d_PB, h->d_flag,
                        h->d_Ab, nAb);
   }
-  if (h->nobs) {
+  if (h->use_pairs) {
+    Timed t(h, MVBA_K_SCHUR);
+    if (h->n_units)
+      hipLaunchKernelGGL(k_schur_pairs, dim3((h->n_units + 3) / 4), dim3(256), 4 * 2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr,
+                         h->d_q_units, h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
+    hipLaunchKernelGGL(k_schur_reduce, dim3(m, m), dim3(128), 0, h->stream, m, h->d_unit_ptr, h->d_partial, d_A, d_b,
+                       h->d_q_head);
+  } else if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
     const bool big = h->nobs * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");  // env: exercise the 64-bit-offset kernels at test sizes
@@ -1642,6 +2021,19 @@ int mvba_get_stats(mvba_handle *h, mvba_stats *out) {
   int rc = sync_and_drain(h);
   if (rc) return rc;
   *out = h->stats;
+  return MVBA_OK;
+}
+
+int mvba_get_info(mvba_handle *h, int64_t *out8) {
+  if (!h || !out8) return fail(MVBA_ERR_BADARG, "null argument");
+  out8[0] = h->n_items;
+  out8[1] = h->n_items_offdiag;
+  out8[2] = h->n_units;
+  out8[3] = h->use_pairs ? 1 : 0;
+  out8[4] = h->rccl_version;
+  out8[5] = NCCL_VERSION_CODE;
+  out8[6] = h->nranks;
+  out8[7] = 0;
   return MVBA_OK;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mvba_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "mvba_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mvba_reset_stats": (C.c_int, [C.c_void_p]),
+    "mvba_get_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mvba_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mvba_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mvba_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]),
@@ -181,6 +182,19 @@ class HipEngine:
         out["counts"] = {"linearize": s.n_linearize, "try_step": s.n_try_step, "commit": s.n_commit,
                          "lu_fallback": s.n_lu_fallback}
         return out
+
+    def _info(self):
+        out = (C.c_int64 * 8)()
+        raise_for(self.lib.mvba_get_info(self._h, out), self.lib)
+        return list(out)
+
+    def schur_info(self):
+        i = self._info()
+        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": "pairs" if i[3] else "strip"}
+
+    def rccl_version(self):
+        i = self._info()
+        return {"loaded": i[4], "compiled_against": i[5], "ranks": i[6]}
 
     def comm_init(self, id128: bytes, rank: int, n_ranks: int):
         buf = C.create_string_buffer(bytes(id128), 128)

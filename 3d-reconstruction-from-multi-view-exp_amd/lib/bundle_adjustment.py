@@ -34,6 +34,39 @@ def dense_to_observations(x: npt.NDArray, visibility_index: npt.NDArray | None):
     return pt_ptr, cam.astype(np.int32), xy
 
 
+def to_gauge_frame(X, R, t, axis: str):
+    """Scene -> the frame BA works in (ref :208-240): camera 0 at the origin with identity pose,
+    camera 1's baseline component along the gauge axis of unit size.  The divisor keeps the
+    reference's quirk: its SIGN comes from the world-frame component of t1 - t0, its
+    MAGNITUDE from the camera-0-frame component."""
+    if axis not in AXES:
+        raise ValueError()
+    g = AXES[axis]  # 0: x-right (index 0), 1: x-up (index 1)
+    R0 = R[0]
+    dX, dt = X - t[0], t - t[0]
+    s = np.sign(dt[1, g]) * (R0[:, g] @ dt[1])
+    s = np.array([s])  # shape (1,), as the reference's
+    return (dX @ R0) / s, R0.T @ R, (dt @ R0) / s
+
+
+def from_gauge_frame(camera0: dict[str, Any], X, R, t):
+    """The way back (ref :242-258): scale by |baseline| (an abs, :23-26), rotate by camera 0's
+    original pose, shift by its original centre."""
+    R0, t0, length = camera0["R"], camera0["t"], camera0["c0c1_len"]
+    return t0 + (length * X) @ R0.T, R0 @ R, t0 + (length * t) @ R0.T
+
+
+def intrinsics_from(f, u, f0: float):
+    """K_k = [[f,0,u0],[0,f,v0],[0,0,f0]] (ref :283-289): K[2,2] is forced to f0."""
+    m = len(f)
+    K = np.zeros((m, 3, 3))
+    K[:, 0, 0] = K[:, 1, 1] = f
+    K[:, 0, 2], K[:, 1, 2] = u[:, 0], u[:, 1]
+    K[:, 2, 2] = f0
+    return K
+
+
+
 class LevenbergMarquardt:
     """The reference's LM control state (:85-101, :118-195) over an engine that
     offers cost / linearize / try_step / commit; ``iterate()`` is one outer
@@ -125,7 +158,7 @@ class BundleAdjuster:
         else:
             raise ValueError()
         self._init_camera0_params = {"R": init_R[0], "t": init_t[0], "c0c1_len": c0c1_len}
-        X, R, t = BundleAdjuster._transform_to_normalize_coodinates(init_X, init_R, init_t, axis=axis)
+        X, R, t = to_gauge_frame(init_X, init_R, init_t, axis)
         self._f0 = f0
         self._n_points, self._n_images = int(n_points), int(n_images)
         self._engine = self._make_engine(self._n_points, self._n_images, pt_ptr, cam_idx, xy, f0, axis, **engine_kw)
@@ -150,37 +183,10 @@ class BundleAdjuster:
 
         lm_loop(self._engine, scale_factor, delta_tol, max_iter, on_state)
         X, f, u, t, R = self._engine.get_params()
-        X, R, t = BundleAdjuster._inverse_transform_to_global_coordinates(self._init_camera0_params, X, R, t)
+        X, R, t = from_gauge_frame(self._init_camera0_params, X, R, t)
         # the reference rebinds its state to the de-normalised values (:198-200)
         self._engine.set_params(X, f, u, t, R)
-        return X, self._get_K(f, u), R, t
+        return X, intrinsics_from(f, u, self._f0), R, t
 
     def get_log(self) -> list[dict[str, npt.NDArray | float]]:
         return self._log
-
-    # -- host-side pieces (ref :208-258, :283-289) ---------------------------------
-    @staticmethod
-    def _transform_to_normalize_coodinates(X, R, t, axis: str = "x-right_z-forward"):
-        X_ = X - t[0]
-        t_ = t - t[0]
-        if axis == "x-right_z-forward":
-            j = np.array([np.sign(t_[1, 0]), 0, 0])
-        elif axis == "x-up_z-forward":
-            j = np.array([0, np.sign(t_[1, 1]), 0])
-        else:
-            raise ValueError()
-        # sign from the world frame, magnitude from camera 0's frame (ref :227-234)
-        s = j @ R[0].T @ t_[1][:, np.newaxis]
-        return (X_ @ R[0]) / s, R[0].T @ R, (t_ @ R[0]) / s
-
-    @staticmethod
-    def _inverse_transform_to_global_coordinates(camera0_param: dict[str, Any], X, R, t):
-        R0, t0, scale = camera0_param["R"], camera0_param["t"], camera0_param["c0c1_len"]
-        return (scale * X) @ R0.T + t0, R0 @ R, (scale * t) @ R0.T + t0
-
-    def _get_K(self, f: npt.NDArray, u: npt.NDArray) -> npt.NDArray:
-        K = np.zeros((self._n_images, 3, 3))
-        K[:, (0, 1), (0, 1)] = f[:, np.newaxis]
-        K[:, :2, 2] = u
-        K[:, 2, 2] = self._f0
-        return K

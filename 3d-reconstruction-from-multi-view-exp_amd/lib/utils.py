@@ -22,14 +22,6 @@ def get_rotation_matrix(omega: NDArray) -> NDArray:
     return (1.0 - c) * np.outer(n, n) + c * np.eye(3) + s * cross
 
 
-def sample_normal_dist(scale: float, n: int) -> NDArray:
-    return np.random.normal(0, scale, (n, 3))
-
-
-def add_noise(X: NDArray, scale: float) -> NDArray:
-    return X + np.random.normal(0, scale, X.shape)
-
-
 def sample_hemisphere_points(num: int, r: float) -> NDArray:
     """Points on the x >= 0 hemisphere of radius r; draws (theta, phi) per point from the
     global NumPy RNG in that order, like the reference (utils.py:40-52), so seeded scenes agree."""

@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: bundle-adjustment LM iterations/s (+ residual-Jacobian GObs/s)
-on BASELINE.json's config 3 -- 1M points x 100 cameras, 10 % visibility, fp64.
+"""Headline benchmark: bundle-adjustment LM iterations/s (+ residual-Jacobian GObs/s), fp64.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE outer Levenberg-Marquardt iteration of the hot path over the
-whole (synthetic, HBM-resident) observation list: K1 residual+Jacobian, K2 point
-blocks, then per trial K3a/K3 Schur, (C1 all-reduce), K4 solve, K5/K6 back-
-substitution + trial cost, commit; the LM control flow is the reference's own
+A "step" is ONE outer Levenberg-Marquardt iteration of the hot path over the whole
+(synthetic, HBM-resident) observation list: K1 residual+Jacobian with K2 point blocks
+fused, then per trial K3a/K3 Schur, (C1 all-reduce), K4 solve, K5/K6 back-substitution +
+trial cost, commit; the LM control flow is the reference's own
 (lib/bundle_adjustment.py:102-195) with optimize(2.0, -1.0, max_iter) semantics.
 
-N > 1 (one process per GPU, launched by torch.distributed.run): WEAK scaling --
-every rank holds a config-3-sized shard (1M points, ~10M observations) of a
-N-times larger scene with the same 100 cameras; the data path exchanges one
-RCCL all-reduce of the reduced camera system per LM solve.  `value` counts
-shard-iterations per second: N * K / t, which is plain it/s at N = 1.
+N = 1   BASELINE config 3: 1M points x 100 cameras, 10 % visibility (the configuration the
+        metric is quoted on).
+N > 1   (one process per GPU, launched by torch.distributed.run)  BASELINE config 4:
+        10M points x 500 cameras, 5 % visibility, STRONG scaling -- the fixed global scene is
+        split by point id into N observation-balanced shards, one RCCL all-reduce of the
+        packed reduced camera system per LM solve.  `value` = plain it/s of the whole job.
+        `--weak` instead gives every rank a config-3-sized shard (round-1 behaviour).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import platform
 import sys
 import time
 
@@ -35,25 +39,47 @@ import numpy as np  # noqa: E402
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_k1_config3.json")
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (f64 FMA issues 16 lanes/clk/SIMD)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_config3.json")
 
 
-def pmc_traffic(n_obs):
-    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes of THIS workload
-    (tools/pmc_run.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)."""
+def pmc_traffic(kernel, n_obs):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes of this workload
+    (tools/final_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB; FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950).  Not measured in
+    this run: the second return value names the file and the commit it was taken at."""
     try:
         d = json.load(open(PMC_FILE))
+        k = d["kernels"][kernel]
         if int(d["n_obs"]) != int(n_obs):
-            return None
-        return (2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024.0
+            return None, None
+        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, f"profiles/pmc_config3.json @ {d.get('commit', '?')}"
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
+
+
+def cpu_info():
+    model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    blas = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in threadpool_info()]
+    except Exception:  # noqa: BLE001
+        pass
+    return {"host_cpus": os.cpu_count(), "cpu_model": model, "blas": blas, "numpy": np.__version__}
 
 
 def svd_config5(rows, cols=24):
     """BASELINE config 5: rows x 24 fp32 measurement-matrix SVD (rank 3) on the GPU; device times
-    from hipEvents inside mvsvd_factorize, HBM-resident (H2D excluded, reported separately)."""
+    from hipEvents inside mvsvd_factorize, HBM-resident (H2D excluded, reported separately).
+    CPU leg: np.linalg.svd(full_matrices=False) on the SAME full matrix, all BLAS threads."""
     from lib import _mvba
 
     rng = np.random.default_rng(0)
@@ -64,47 +90,64 @@ def svd_config5(rows, cols=24):
     M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 3)
     dev_ms = tm["gram_ms"] + tm["jacobi_ms"] + tm["project_ms"]
     alg = 2 * rows * cols * 4 + 3 * rows * 4
-    n_cpu = min(rows, 500_000)
     t0 = time.perf_counter()
-    np.linalg.svd(Wt[:n_cpu], full_matrices=False)
-    cpu_s = (time.perf_counter() - t0) * rows / n_cpu
+    sig_cpu = np.linalg.svd(Wt, full_matrices=False, compute_uv=True)[1]
+    cpu_s = time.perf_counter() - t0
     return {"workload": f"{rows} x {cols} fp32, rank 3", "device_ms": dev_ms, "h2d_ms": tm["h2d_ms"],
             "gram_ms": tm["gram_ms"], "jacobi_ms": tm["jacobi_ms"], "project_ms": tm["project_ms"],
             "algorithmic_bytes": alg, "achieved_GBs": alg / (dev_ms * 1e-3) / 1e9,
             "frac_of_hbm_peak": alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "cpu_numpy_thin_svd_s": cpu_s, "cpu_sample_rows": n_cpu, "sigma": [float(x) for x in sig[:4]]}
+            "cpu_numpy_thin_svd_s": cpu_s, "cpu_rows": rows,
+            "sigma": [float(x) for x in sig[:4]], "sigma_cpu": [float(x) for x in sig_cpu[:4]]}
 
 
-def cpu_baseline(n_points_full, n_images, vis_p, n_obs_full, sample_points):
+def cpu_baseline(sc, n_images, iters=3, workers=None, config2=True):
     """The oracle (NumPy/SciPy restatement of the reference, pinned by golden vectors) timed on
-    this host on a bounded sample of the same workload, scaled by observation count."""
-    from threadpoolctl import threadpool_limits
-
-    from lib.synthetic import make_scene
+    this host.  (i) config 3 ITSELF, `iters` outer LM iterations of optimize(2.0, -1.0, iters), on
+    all host cores: one oracle engine per worker process on a point shard (oracle/ba_parallel.py;
+    NumPy's own kernels are single-threaded).  (ii) config 2 (10k x 20, full visibility) with the
+    dense-faithful restatement of the reference's algorithm (oracle/ba_dense.py), 2 iterations."""
+    from lib.bundle_adjustment import lm_loop
     from oracle import ba_oracle as O
+    from oracle.ba_parallel import ShardedOracle
 
-    sc = make_scene(n_points_full, n_images, vis_p=vis_p, point_range=(0, sample_points))
-    g = O.OracleEngine(sc.n_points, n_images, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    info = cpu_info()
+    workers = int(workers or min(os.cpu_count() or 1, 64))
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
-    g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
-    with threadpool_limits(limits=1):
-        E = g.cost()
-        t0 = time.perf_counter()
-        g.linearize()
-        t1 = time.perf_counter()
-        E1 = g.try_step(1e-4)
-        g.commit()
-        t2 = time.perf_counter()
-    assert E1 < E
-    scale = n_obs_full / sc.n_obs
-    it_s = 1.0 / ((t2 - t0) * scale)
-    return {
-        "value": it_s, "unit": "it/s", "cores": 1, "kind": "port",
-        "sample": f"oracle/ba_oracle.py, 1 LM iteration on the first {sample_points} points x {n_images} cameras "
-                  f"({sc.n_obs} obs) of the same scene, {t2 - t0:.2f} s, scaled x{scale:.1f} by observation count",
-        "resid_jac_gobs_s": sc.n_obs / (t1 - t0) / 1e9,
-        "host_cpus": os.cpu_count(),
+    t0 = time.perf_counter()
+    g = ShardedOracle(sc.n_points, n_images, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis, X, sc.init_K[:, 0, 0],
+                      sc.init_K[:, :2, 2], t, R, n_workers=workers)
+    E0 = g.cost()
+    t1 = time.perf_counter()
+    E = lm_loop(g, 2.0, -1.0, iters, verbose=False)
+    t2 = time.perf_counter()
+    solves = g.n_solves
+    g.close()
+    out = {
+        "value": iters / (t2 - t1), "unit": "it/s", "cores": workers, "kind": "port",
+        "sample": f"oracle/ba_parallel.py: the WHOLE config-3 scene ({sc.n_points} points x {n_images} cameras, {sc.n_obs} "
+                  f"observations), optimize(2.0, -1.0, {iters}) = {iters} outer LM iterations / {solves} solves in {t2 - t1:.1f} s on "
+                  f"{workers} worker processes (one point shard each, 1 BLAS thread per worker); setup {t1 - t0:.1f} s not counted",
+        "rmse_start": float(np.sqrt(E0 / sc.n_obs)), "rmse_end": float(np.sqrt(E / sc.n_obs)), **info,
     }
+    if config2:
+        try:
+            from lib.synthetic import make_scene
+            from oracle import ba_dense as Dn
+
+            s2 = make_scene(10_000, 20, vis_p=1.0)
+            x, vis = s2.dense()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                ba = Dn.DenseBundleAdjuster(x, s2.init_X, s2.init_K, s2.init_R, s2.init_t, axis=s2.axis)
+                ba.optimize(2.0, -1.0, max_iter=2)
+            dt = time.perf_counter() - t0
+            out["dense_faithful_config2"] = {"it_per_s": 2 / dt, "mobs_per_s": 2 * s2.n_obs / dt / 1e6, "iterations": 2,
+                                             "seconds": dt, "workload": "10k points x 20 cameras, full visibility",
+                                             "kind": "oracle/ba_dense.py (dense broadcast algorithm of ref :103-162), BLAS threads as listed"}
+        except Exception as exc:  # noqa: BLE001
+            out["dense_faithful_config2"] = {"error": repr(exc)}
+    return out
 
 
 def main():
@@ -112,10 +155,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=1_000_000, help="points per GPU")
-    ap.add_argument("--cams", type=int, default=100)
-    ap.add_argument("--vis", type=float, default=0.1)
-    ap.add_argument("--cpu-sample-points", type=int, default=100_000)
+    ap.add_argument("--points", type=int, default=None, help="global points (default: 1M at N=1, 10M at N>1)")
+    ap.add_argument("--cams", type=int, default=None)
+    ap.add_argument("--vis", type=float, default=None)
+    ap.add_argument("--weak", action="store_true", help="N>1: a config-3-sized shard per GPU instead of config 4 split N ways")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
     args = ap.parse_args()
@@ -141,12 +186,26 @@ def main():
 
     from lib import _distributed, _mvba
     from lib.bundle_adjustment import BundleAdjuster, LevenbergMarquardt
-    from lib.synthetic import make_scene
+    from lib.synthetic import make_scene, scene_shard
 
-    n_total = args.points * world
-    sc = make_scene(n_total, args.cams, vis_p=args.vis, point_range=(rank * args.points, (rank + 1) * args.points))
-    ba = BundleAdjuster.from_observations(sc.n_points, args.cams, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+    config4 = world > 1 and not args.weak
+    n_cams = args.cams or (500 if config4 else 100)
+    vis = args.vis or (0.05 if config4 else 0.1)
+    if config4:
+        n_total = args.points or 10_000_000
+        lo, hi = scene_shard(n_total, n_cams, vis, rank, world)  # observation-balanced contiguous point ranges
+        scaling, cfg_name = "strong", "BASELINE config 4"
+    else:
+        per = args.points or 1_000_000
+        n_total, lo, hi = per * world, rank * per, (rank + 1) * per
+        scaling, cfg_name = "weak", "BASELINE config 3" + (" shard per GPU" if world > 1 else "")
+    t_gen = time.perf_counter()
+    sc = make_scene(n_total, n_cams, vis_p=vis, point_range=(lo, hi))
+    t_gen = time.perf_counter() - t_gen
+    t_create = time.perf_counter()
+    ba = BundleAdjuster.from_observations(sc.n_points, n_cams, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                           sc.init_R, sc.init_t, axis=sc.axis, device=local_rank)
+    t_create = time.perf_counter() - t_create
     eng = ba._engine
     if multi:
         _distributed.attach_rccl(eng)
@@ -191,10 +250,25 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
+    n_solves = eng.n_solves - solves0
+    eng.set_profiling(False)
+
+    # The same schedule through the PUBLIC surface: BundleAdjuster.optimize(2.0, -1.0, 10)
+    # wall time -- includes the per-iteration print, the final get_params, the way back to the input
+    # frame and the set_params the reference's optimize ends with (ref :198-202).
+    eng.set_params(*state0)
+    API_ITERS = 10
+    fence()
+    ta = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ba.optimize(2.0, -1.0, max_iter=API_ITERS)
+    fence()
+    t_api = time.perf_counter() - ta
+
     if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, t_api], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, t_api = float(tt[0].item()), float(tt[1].item())
         no = torch.tensor([sc.n_obs], dtype=torch.float64, device="cuda")
         dist.all_reduce(no)
         n_obs_total = int(no.item())
@@ -202,45 +276,77 @@ def main():
         n_obs_total = sc.n_obs
 
     if rank == 0:
-        k1 = st["resid_jac"]
-        k1_ms = k1["ms"] / max(k1["launches"], 1)
+        per = {k: v["ms"] / max(v["launches"], 1) for k, v in st.items() if k != "counts"}
+        k1_ms, k3_ms = per["resid_jac"], per["schur"]
         # K1 algorithmic bytes per launch on this rank: in xy 16 + cam 4 + point id 4,
         # out ONE 128-B record per observation (the 2x9 block's t and (u,v) columns are implied),
         # + per point 24 B in (X) and 72 B out (E_a, dP_a: K2 is fused into K1).
         # (SURVEY 8d's 232 B/obs assumed the 208-B materialised 2x9 form and a separate K2.)
-        alg_bytes = 152 * sc.n_obs + 96 * sc.n_points
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+        k1_bytes = 152 * sc.n_obs + 96 * sc.n_points
+        k1_ach = k1_bytes / (k1_ms * 1e-3) / 1e9
+        k1_traffic, k1_src = pmc_traffic("k_resid_jac", sc.n_obs)
+        # K3 (the dominant kernel): SURVEY 8d's algorithmic read is 192 B/observation (J_X 48 + J_C 144);
+        # what the pair-major kernel actually gathers is one 128-B record line per side of every
+        # (point, camera pair) item + the point block, and its arithmetic is
+        # ~100 fp64 FMA per lane-step of 21 items x 3 lanes.
+        ms_solve = dt / max(n_solves, 1) * 1e3
+        info = eng.schur_info()
+        k3_bytes = 192 * sc.n_obs
+        k3_ach = k3_bytes / (k3_ms * 1e-3) / 1e9
+        k3_traffic, k3_src = pmc_traffic("k_schur_pairs", sc.n_obs)
+        gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
+        flops = info["items"] * 3 * 96 * 2
+        roof_k3 = {"kernel": "k_schur_pairs (K3)", "bound": "hbm", "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,
+                   "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
+                   "algorithmic_bytes_per_launch": k3_bytes, "algorithmic_bytes_per_obs": 192, "avg_launch_ms": k3_ms,
+                   "items": info["items"], "units": info["units"],
+                   "gathered_bytes_per_launch": gather, "gather_GBs": gather / (k3_ms * 1e-3) / 1e9,
+                   "fp64_tflops": flops / (k3_ms * 1e-3) / 1e12,
+                   "frac_of_fp64_valu_peak": flops / (k3_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+        roof_k1 = {"kernel": "k_resid_jac (K1+K2)", "bound": "hbm", "achieved": k1_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": k1_ach / HBM_PEAK_GBS, "traffic": k1_traffic, "traffic_source": k1_src,
+                   "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
+                   "algorithmic_bytes_per_launch": k1_bytes, "algorithmic_bytes_per_obs": 152, "avg_launch_ms": k1_ms}
+        step_bytes = 824 * sc.n_obs  # K1 232 + K2 208 + K3 192 + K5 192 B/obs per inner solve
         rmse = float(np.sqrt(E_ / n_obs_total))
         out = {
             "metric": "BA iterations/sec + residual-Jacobian GObs/s, 1M pts x 100 cams fp64",
-            "value": world * args.steps / dt,
+            "value": (world if scaling == "weak" else 1) * args.steps / dt,
             "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE config 3: {args.points} points x {args.cams} cameras, {args.vis:.0%} visibility, "
-                            f"fp64, per GPU ({sc.n_obs} observations on rank 0); LM optimize(2.0, -1.0, max_iter) schedule",
-                "points_per_gpu": args.points, "cameras": args.cams, "visibility": args.vis,
-                "observations_total": n_obs_total, "reduced_system_dim": 9 * args.cams - 7,
-                "value_definition": "outer LM iterations x point shards per second (= it/s at 1 GPU)",
+                "workload": f"{cfg_name}: {n_total} points x {n_cams} cameras, {vis:.0%} visibility, fp64, "
+                            f"{n_obs_total} observations in total ({sc.n_obs} on rank 0), point-sharded over {world} GPU(s); "
+                            f"LM optimize(2.0, -1.0, max_iter) schedule",
+                "points_total": n_total, "points_rank0": sc.n_points, "cameras": n_cams, "visibility": vis,
+                "observations_total": n_obs_total, "reduced_system_dim": 9 * n_cams - 7,
+                "value_definition": "outer LM iterations per second of the whole job"
+                                    + (" x point shards (weak scaling: every rank holds a config-3 shard)" if scaling == "weak" and world > 1 else ""),
                 "episode_iterations": EPISODE, "episode_restarts_in_timed_region": n_restarts - restarts0,
+                "scene_generation_s": t_gen, "engine_create_s": t_create,
+                "rccl": eng.rccl_version() if multi else None,
             },
-            "resid_jac_gobs_per_s": world * sc.n_obs / (k1_ms * 1e-3) / 1e9,
-            "inner_solves": eng.n_solves - solves0,
-            "ms_per_inner_solve": dt / max(eng.n_solves - solves0, 1) * 1e3,
+            "resid_jac_gobs_per_s": n_obs_total / (k1_ms * 1e-3) / 1e9,
+            "inner_solves": n_solves,
+            "ms_per_inner_solve": ms_solve,
             "rmse_start": float(np.sqrt(E0 / n_obs_total)), "rmse_end": rmse,
-            "roofline": {"kernel": "k_resid_jac", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(sc.n_obs),
-                         "traffic_unit": "bytes per launch (PMC)", "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_per_obs": 152, "avg_launch_ms": k1_ms},
+            "optimize_api": {"call": f"BundleAdjuster.optimize(2.0, -1.0, max_iter={API_ITERS})", "wall_s": t_api,
+                             "it_per_s": API_ITERS / t_api},
+            "roofline": roof_k3 if k3_ms >= k1_ms else roof_k1,
+            "roofline_resid_jac": roof_k1,
+            "roofline_schur": roof_k3,
+            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_solve": step_bytes, "bytes_per_obs": 824,
+                              "achieved": step_bytes / (ms_solve * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
         }
         if not args.no_cpu_baseline and world == 1:  # CPU baseline and SVD leg: rank 0 at N = 1 only
             eng.close()
-            out["cpu_baseline"] = cpu_baseline(n_total, args.cams, args.vis, n_obs_total,
-                                               min(args.cpu_sample_points, args.points))
+            out["cpu_baseline"] = cpu_baseline(sc, n_cams, iters=args.cpu_iters, workers=args.cpu_workers)
             if args.svd_rows > 0:
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
         print(json.dumps(out))

@@ -101,6 +101,13 @@ int mvba_set_profiling(mvba_handle *h, int32_t enabled);
 int mvba_get_stats(mvba_handle *h, mvba_stats *out);
 int mvba_reset_stats(mvba_handle *h);
 
+/* Sizes of the Schur index built at create and what the communicator runs on (bench.py prices the
+ * kernels with them): out[0] (point, camera pair) items incl. diagonal pairs, out[1] off-diagonal
+ * items, out[2] units (wave runs), out[3] 1 = pair-major Schur kernel / 0 = strip kernel,
+ * out[4] ncclGetVersion() of the librccl actually loaded (0 without a communicator), out[5] the
+ * NCCL_VERSION_CODE the library was compiled against, out[6] ranks, out[7] reserved. */
+int mvba_get_info(mvba_handle *h, int64_t *out8);
+
 /* Point-sharded multi-GPU (one process per GPU): rank 0 makes an id, the host
  * side ships its 128 bytes to the other ranks, every rank calls comm_init.
  * Afterwards try_step all-reduces the partial reduced system [A|b] over RCCL and

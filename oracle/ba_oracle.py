@@ -258,6 +258,11 @@ class OracleEngine:
             packed = np.concatenate([A.reshape(-1), b])
             self.allreduce(packed)
             A, b = packed[:-b.size].reshape(A.shape), packed[-b.size:]
+        dxi = self.solve_reduced(A, b)
+        return self._global_sum(self.apply_step(dxi))
+
+    def solve_reduced(self, A, b):
+        """Gauge rows/columns out (ref :62-72), dense solve (ref :146); returns the full (9m,) increment."""
         self.A = A[np.ix_(self.keep, self.keep)]
         self.b = b[self.keep]
         dxi_red = np.linalg.solve(self.A, self.b)  # ref :146
@@ -265,7 +270,11 @@ class OracleEngine:
         dxi = np.zeros(9 * self.m)
         dxi[self.keep] = dxi_red
         self.dxi_red = dxi_red
-        dxi = dxi.reshape(self.m, 9)
+        return dxi
+
+    def apply_step(self, dxi):
+        """Back-substitution, trial state and this engine's share of the trial cost (ref :152-162, :260-281)."""
+        dxi = np.asarray(dxi).reshape(self.m, 9)
         Fd = np.einsum("oij,oj->oi", self.F, dxi[self.cam])
         self.dX = -np.einsum("aij,aj->ai", self.Einv, _segsum(self.pt, Fd, self.n) + self.dP)  # ref :152
         self.tX = self.X + self.dX  # ref :260-261
@@ -273,8 +282,7 @@ class OracleEngine:
         self.tu = self.u + dxi[:, 1:3]
         self.tt = self.t + dxi[:, 3:6]
         self.tR = np.stack([rodrigues(w) for w in dxi[:, 6:9]]) @ self.R
-        return self._global_sum(
-            cost(self.tX, self.tf, self.tu, self.tt, self.tR, self.f0, self.pt, self.cam, self.xy))
+        return cost(self.tX, self.tf, self.tu, self.tt, self.tR, self.f0, self.pt, self.cam, self.xy)
 
     def commit(self):
         self.X, self.f, self.u, self.t, self.R = self.tX, self.tf, self.tu, self.tt, self.tR
