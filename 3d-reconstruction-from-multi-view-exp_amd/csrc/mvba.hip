@@ -18,6 +18,7 @@
 // constants (1/f0,0),(0,1/f0) (ref :350-376), so the 2x9 block is implied by the
 // record.  A point's observations are consecutive lines, which is what makes the
 // camera-major Schur gather cheap (one line per (point,camera) pair).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -33,6 +34,67 @@ namespace mvba {
 thread_local std::string g_err;
 }
 using namespace mvba;
+
+// ------------------------------------------------------------------ RCCL binding
+// libmvba.so is NOT linked against librccl: a process may already hold one (PyTorch maps its own
+// bundled librccl.so the moment torch.distributed creates a group), and two copies -- or headers of
+// one release bound to the code of another by accident of load order -- is the version skew a
+// collective library does not forgive.  The policy is explicit instead: use the librccl the
+// process has ALREADY loaded if there is one (RTLD_NOLOAD), else load ROCm's; bind the seven entry
+// points by name (all part of the NCCL 2.x C API: plain pointers, enums whose values have not
+// changed since 2.0, the 128-byte id), and refuse a library whose major version differs from the
+// headers this file was compiled against.  mvba_get_info reports both versions.
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  int version = 0;
+  std::string origin;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return MVBA_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so"};
+  void *lib = nullptr;
+  std::string origin;
+  for (const char *n : names)
+    if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) origin = std::string(n) + " (already mapped by the process)";
+  if (const char *ev = getenv("MVBA_RCCL_LIBRARY"))
+    if (!lib && (lib = dlopen(ev, RTLD_NOW | RTLD_GLOBAL))) origin = ev;
+  for (const char *n : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1"})
+    if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) origin = n;
+  if (!lib) return fail(MVBA_ERR_RCCL, std::string("librccl not found: ") + dlerror());
+  Rccl r;
+  r.lib = lib;
+  r.origin = origin;
+#define BIND(field, sym)                                                                       \
+  if (!(r.field = reinterpret_cast<decltype(r.field)>(dlsym(lib, sym))))                       \
+    return fail(MVBA_ERR_RCCL, std::string("librccl (") + origin + ") lacks " + sym)
+  BIND(GetVersion, "ncclGetVersion");
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(AllReduce, "ncclAllReduce");
+  BIND(AllGather, "ncclAllGather");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  if (r.GetVersion(&r.version) != ncclSuccess) return fail(MVBA_ERR_RCCL, "ncclGetVersion failed");
+  // version code: major * 10000 + minor * 100 + patch since 2.9 (major * 1000 + ... before)
+  const int major = r.version >= 10000 ? r.version / 10000 : r.version / 1000;
+  if (major != NCCL_MAJOR)
+    return fail(MVBA_ERR_RCCL, "librccl (" + origin + ") is NCCL " + std::to_string(r.version) + ", this library was built against " +
+                                   std::to_string(NCCL_VERSION_CODE));
+  g_rccl = r;
+  return MVBA_OK;
+}
+}  // namespace
 
 // ------------------------------------------------------------------ device helpers
 namespace {
@@ -1483,14 +1545,16 @@ int sync_and_drain(mvba_handle *h) {
   return MVBA_OK;
 }
 
-// sum of per-rank costs in rank order (identical on every rank)
+// Sum of the per-rank costs in rank order and the OR of the per-rank status flags: both identical on
+// every rank, so that all ranks take the same accept/reject, LU-rescue and error decisions (a
+// rank that branched alone would leave the others waiting in the next collective).  (C1b: one
+// all-gather of 16 bytes per rank per trial, on top of C1.)
 int global_cost(mvba_handle *h, double *E) {
   if (h->comm) {
     Timed t(h, MVBA_K_ALLREDUCE);
-    ncclResult_t r = ncclAllGather(h->d_cost, h->d_allcost, 1, ncclDouble, h->comm, h->stream);
-    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
-    MVBA_HIP(hipMemcpyAsync(h->h_allcost, h->d_allcost, sizeof(double) * h->nranks, hipMemcpyDeviceToHost, h->stream));
-    MVBA_HIP(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ncclResult_t r = g_rccl.AllGather(h->d_cost, h->d_allcost, 2, ncclDouble, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+    MVBA_HIP(hipMemcpyAsync(h->h_allcost, h->d_allcost, 2 * sizeof(double) * h->nranks, hipMemcpyDeviceToHost, h->stream));
   } else {
     MVBA_HIP(hipMemcpyAsync(h->h_cost, h->d_cost, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));  // cost + flags
   }
@@ -1498,8 +1562,15 @@ int global_cost(mvba_handle *h, double *E) {
   if (rc) return rc;
   if (h->comm) {
     double s = 0.0;
-    for (int i = 0; i < h->nranks; ++i) s += h->h_allcost[i];
+    int fl = 0;
+    for (int i = 0; i < h->nranks; ++i) {
+      s += h->h_allcost[2 * i];
+      int f;
+      memcpy(&f, &h->h_allcost[2 * i + 1], sizeof(int));
+      fl |= f;
+    }
     *E = s;
+    *h->h_flag = fl;
   } else {
     *E = *h->h_cost;
   }
@@ -1813,7 +1884,7 @@ void mvba_destroy(mvba_handle *h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  if (h->comm) ncclCommDestroy(h->comm);
+  if (h->comm) g_rccl.CommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
@@ -1925,8 +1996,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   MVBA_HIP(hipGetLastError());
   if (h->comm) {
     Timed t(h, MVBA_K_ALLREDUCE);
-    ncclResult_t r = ncclAllReduce(h->d_Ab, h->d_Ab, nA + n9, ncclDouble, ncclSum, h->comm, h->stream);
-    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    ncclResult_t r = g_rccl.AllReduce(h->d_Ab, h->d_Ab, nA + n9, ncclDouble, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
   }
   {
     Timed t(h, MVBA_K_SOLVE);
@@ -2049,9 +2120,10 @@ int mvba_reset_stats(mvba_handle *h) {
 int mvba_comm_unique_id(void *id128) {
   if (!id128) return fail(MVBA_ERR_BADARG, "null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  if (int rc = rccl_load()) return rc;
   ncclUniqueId id;
-  ncclResult_t r = ncclGetUniqueId(&id);
-  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
   memcpy(id128, &id, 128);
   return MVBA_OK;
 }
@@ -2059,14 +2131,16 @@ int mvba_comm_unique_id(void *id128) {
 int mvba_comm_init(mvba_handle *h, const void *id128, int32_t rank, int32_t n_ranks) {
   if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MVBA_ERR_BADARG, "bad comm arguments");
   MVBA_HIP(hipSetDevice(h->device));
+  if (int rc = rccl_load()) return rc;
   ncclUniqueId id;
   memcpy(&id, id128, 128);
-  ncclResult_t r = ncclCommInitRank(&h->comm, n_ranks, id, rank);
-  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  ncclResult_t r = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
   h->rank = rank; h->nranks = n_ranks;
-  int rc = dmalloc(&h->d_allcost, n_ranks);
+  h->rccl_version = g_rccl.version;
+  int rc = dmalloc(&h->d_allcost, 2 * (size_t)n_ranks);
   if (rc) return rc;
-  MVBA_HIP(hipHostMalloc((void **)&h->h_allcost, sizeof(double) * n_ranks));
+  MVBA_HIP(hipHostMalloc((void **)&h->h_allcost, 2 * sizeof(double) * n_ranks));
   return MVBA_OK;
 }
 

@@ -172,3 +172,11 @@ def make_scene(n_points, n_images, vis_p=1.0, seed=0, vis_seed=1, perturb_seed=2
     np.cumsum(np.bincount(pt, minlength=n_loc), out=pt_ptr[1:])
     return Scene(n_loc, n_images, lo, pt_ptr, np.concatenate(cams), np.concatenate(xys),
                  np.concatenate(Xs), K, R, t, np.concatenate(X0s), K0, R0, t0)
+
+
+def scene_shard(n_points, n_images, vis_p, rank, world):
+    """Point range [lo, hi) of rank ``rank`` when the global scene is split ``world`` ways.
+    Visibility is iid per (point, camera), so equal point counts are observation-balanced to
+    ~1/sqrt(n_obs); ``lib._distributed.partition_points`` does the exact split when a global
+    ``pt_ptr`` exists (it never does at config-4 size: 250 M observations)."""
+    return n_points * rank // world, n_points * (rank + 1) // world

@@ -129,11 +129,13 @@ def test_bench_cpu_baseline_and_pmc_helpers():
     import bench
 
     sc = make_scene(4000, 8, vis_p=0.5)
-    cb = bench.cpu_baseline(4000, 8, 0.5, sc.n_obs, 1000)
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "it/s" and cb["value"] > 0
-    assert "1000 points" in cb["sample"]
+    cb = bench.cpu_baseline(sc, 8, iters=2, workers=2, config2=False)
+    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["unit"] == "it/s" and cb["value"] > 0
+    assert "4000 points" in cb["sample"] and cb["host_cpus"] == os.cpu_count() and cb["rmse_end"] < cb["rmse_start"]
     d = json.load(open(bench.PMC_FILE))
-    t = bench.pmc_traffic(d["n_obs"])
-    assert t == pytest.approx((2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
+    k1 = d["kernels"]["k_resid_jac"]
+    t, src = bench.pmc_traffic("k_resid_jac", d["n_obs"])
+    assert t == pytest.approx((2 * k1["FETCH_SIZE_KiB"] + k1["WRITE_SIZE_KiB"]) * 1024) and "pmc_config3.json" in src
     assert 0.95 < t / (152 * d["n_obs"] + 96 * d["n_points"]) < 1.10  # HBM traffic ~ algorithmic bytes
-    assert bench.pmc_traffic(d["n_obs"] + 1) is None
+    assert bench.pmc_traffic("k_resid_jac", d["n_obs"] + 1) == (None, None)
+    assert bench.pmc_traffic("no_such_kernel", d["n_obs"]) == (None, None)

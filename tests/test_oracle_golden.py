@@ -80,6 +80,50 @@ def test_full_trajectory(golden, name, axis, args):
     np.testing.assert_allclose(t, d["out_t"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("name,axis,args", [
+    ("euclid_default", "x-up_z-forward", (2.0, 1e-8, 100)),
+    ("visibility_300x12", "x-up_z-forward", (2.0, -1.0, 10)),
+    ("linearize_60x7_xright", "x-right_z-forward", (10.0, 1e-8, 8)),
+])
+def test_dense_faithful_oracle_full_trajectory(golden, name, axis, args):
+    """oracle/ba_dense.py (the reference's dense broadcast form, timed as the CPU baseline at
+    configs 1-2) reproduces the reference's trajectories: same iteration and solve counts, RMSE 1e-9."""
+    from oracle import ba_dense as Dn
+
+    d = golden(name)
+    vis = d["vis"] if "vis" in d.files else None
+    ba = Dn.DenseBundleAdjuster(d["x"], d["init_X"], d["init_K"], d["init_R"], d["init_t"],
+                                visibility_index=vis, axis=axis)
+    X, K, R, t = ba.optimize(*args, is_debug=True, verbose=False)
+    E = np.array([e["reprojection_error"] for e in ba.get_log()])
+    assert len(E) == len(d["E_log"]) and ba.engine.n_solves == int(d["n_solves"])
+    n_obs = int(ba.engine.v.sum())
+    assert abs(np.sqrt(E[-1] / n_obs) - np.sqrt(d["E_log"][-1] / n_obs)) < 1e-9
+    np.testing.assert_allclose(E, d["E_log"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(X, d["out_X"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(R, d["out_R"], rtol=0, atol=1e-6)
+
+
+def test_sharded_all_cores_oracle_equals_single_engine(golden):
+    """oracle/ba_parallel.py (bench.py's all-cores cpu_baseline) == one OracleEngine on the same scene."""
+    from lib.bundle_adjustment import lm_loop
+    from oracle.ba_parallel import ShardedOracle
+
+    d = golden("visibility_300x12")
+    axis = "x-up_z-forward"
+    g = _engine_from(d, axis)
+    X, f, u, t, R = g.get_params()
+    p = ShardedOracle(g.n, g.m, g.pt_ptr, g.cam, g.xy, 1.0, axis, X, f, u, t, R, n_workers=3)
+    try:
+        E1 = lm_loop(g, 2.0, -1.0, 4, verbose=False)
+        E2 = lm_loop(p, 2.0, -1.0, 4, verbose=False)
+        assert g.n_solves == p.n_solves
+        assert abs(E1 - E2) <= 1e-12 * E1
+        np.testing.assert_allclose(p.points(), g.X, rtol=0, atol=1e-11)
+    finally:
+        p.close()
+
+
 def test_euclid_default_headline_numbers(golden):
     d = golden("euclid_default")
     assert int(d["n_outer"]) == 37 and int(d["n_solves"]) == 59
