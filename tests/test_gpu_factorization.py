@@ -90,6 +90,44 @@ def test_large_tall_skinny_properties(dtype, n_cols):
     np.testing.assert_allclose(sigc[:3].astype(np.float64), sig_c_ref[:3], rtol=tol)
 
 
+def test_config5_full_size_5m_rows_fp32():
+    """BASELINE config 5 at its stated size: 5,000,000 x 24 fp32, rank 3 (ref factorization.py:10-13;
+    centring as affine_camera_calibration.py:224-240).  Same property set as the 1M-row test, judged
+    against an fp64 LAPACK SVD of the same data."""
+    import os
+    import time
+
+    n_rows, n_cols = 5_000_000, 24
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n_rows, 3), dtype=np.float32)
+    B = rng.standard_normal((3, n_cols), dtype=np.float32)
+    Wt = A @ B + np.float32(1e-3) * rng.standard_normal((n_rows, n_cols), dtype=np.float32)
+    del A
+    t0 = time.perf_counter()
+    M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 3)
+    wall = time.perf_counter() - t0
+    W64 = Wt.astype(np.float64)
+    sig_ref = np.linalg.svd(W64, compute_uv=False)
+    np.testing.assert_allclose(sig[:3].astype(np.float64), sig_ref[:3], rtol=1e-6)
+    M64, S64 = M.astype(np.float64), S.astype(np.float64)
+    np.testing.assert_allclose(M64.T @ M64, np.eye(3), atol=1e-5)
+    np.testing.assert_allclose(S64, M64.T @ W64.T, rtol=0, atol=1e-4 * np.abs(S64).max())
+    np.testing.assert_allclose(np.linalg.norm(S64, axis=1), sig_ref[:3], rtol=1e-5)
+    assert np.abs(W64[:20000] - (M64 @ S64[:, :20000]).T).max() < 1e-2
+    Mc, sigc, Sc, muc, _ = _mvba.svd_factorize(Wt, 3, center=True)
+    np.testing.assert_allclose(muc.astype(np.float64), W64.mean(axis=0), rtol=0, atol=1e-5)
+    sig_c_ref = np.linalg.svd(W64 - W64.mean(axis=0), compute_uv=False)
+    np.testing.assert_allclose(sigc[:3].astype(np.float64), sig_c_ref[:3], rtol=1e-6)
+    line = (f"config 5 (5,000,000 x 24 fp32, rank 3): device {tm['gram_ms'] + tm['jacobi_ms'] + tm['project_ms']:.3f} ms "
+            f"(gram {tm['gram_ms']:.3f}, jacobi {tm['jacobi_ms']:.3f}, project {tm['project_ms']:.3f}), H2D {tm['h2d_ms']:.1f} ms, "
+            f"call wall {wall * 1e3:.1f} ms")
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "fullsize_timings.txt"), "a") as fh:
+            fh.write(line + "\n")
+    print(line)
+
+
 def test_bad_arguments():
     with pytest.raises(ValueError):
         _mvba.svd_factorize(np.zeros((10, 4)), 5)
