@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "mvba_common.h"
@@ -1441,6 +1442,40 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict_
   }
 }
 
+// ------------------------------------------------------------------ projection (scene side of BA)
+// x_o = K_k [R_k^T | -R_k^T t_k] [X_a; 1], inhomogeneous (ref lib/camera.py:13-14 get_camera_matrix,
+// :30-34 project_points, :74-81 calc_projected_points) for an observation list.  The 3x4 camera
+// matrices are formed once per block in LDS in the reference's order of operations (K times the
+// stacked [R^T, -R^T t]); one thread per observation, coalesced reads of the index arrays and a
+// coalesced 16-byte store.  obs_pt == nullptr: dense grid, observation o = point * m + camera.
+__global__ __launch_bounds__(256) void k_project_obs(long long nobs, int m, const double *__restrict__ X,
+                                                     const double *__restrict__ K, const double *__restrict__ R,
+                                                     const double *__restrict__ t, const int *__restrict__ obs_pt,
+                                                     const int *__restrict__ cam_idx, double2 *__restrict__ xy) {
+  extern __shared__ double sP[];  // [m][12]
+  for (int k = threadIdx.x; k < m; k += blockDim.x) {
+    const double *Kk = K + 9 * (size_t)k, *Rk = R + 9 * (size_t)k, *tk = t + 3 * (size_t)k;
+    double Rt[3][4];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rt[i][j] = Rk[3 * j + i];
+      Rt[i][3] = -(Rt[i][0] * tk[0] + Rt[i][1] * tk[1] + Rt[i][2] * tk[2]);
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) sP[12 * k + 4 * i + j] = Kk[3 * i] * Rt[0][j] + Kk[3 * i + 1] * Rt[1][j] + Kk[3 * i + 2] * Rt[2][j];
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < nobs; o += stride) {
+    const long long a = obs_pt ? obs_pt[o] : o / m;
+    const int k = cam_idx ? cam_idx[o] : (int)(o - a * m);
+    const double *Xa = X + 3 * a, *P = sP + 12 * k;
+    const double p0 = Xa[0] * P[0] + Xa[1] * P[1] + Xa[2] * P[2] + P[3];
+    const double p1 = Xa[0] * P[4] + Xa[1] * P[5] + Xa[2] * P[6] + P[7];
+    const double p2 = Xa[0] * P[8] + Xa[1] * P[9] + Xa[2] * P[10] + P[11];
+    xy[o] = make_double2(p0 / p2, p1 / p2);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host side
@@ -1716,14 +1751,27 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     const long long P = (long long)m * (m + 1) / 2;
     auto pair_id = [m](int k, int l) { return (long long)k * m - (long long)k * (k - 1) / 2 + (l - k); };
     std::vector<long long> cnt(P, 0);
-    for (long long a = 0; a < N; ++a) {
-      const int *cb = p->cam_idx + p->pt_ptr[a];
-      const int d = (int)(p->pt_ptr[a + 1] - p->pt_ptr[a]);
-      for (int i = 0; i < d; ++i) {
-        long long *row = cnt.data() + pair_id(cb[i], cb[i]) - cb[i];  // row[l] = cnt[pair(k, l)]
-        for (int j = i; j < d; ++j) row[cb[j]]++;
+    // Both passes over the points run on host threads that OWN strips (camera k belongs to thread
+    // k % n_thr): every thread scans the whole observation list but touches only its own pairs, so
+    // there is nothing to lock and the order inside a pair's list stays ascending by point.
+    const int n_thr = (int)std::max(1u, std::min({std::thread::hardware_concurrency(), 16u, (unsigned)m}));
+    auto on_threads = [&](auto body) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < n_thr; ++t) th.emplace_back(body, t);
+      body(0);
+      for (auto &x : th) x.join();
+    };
+    on_threads([&](int tid) {
+      for (long long a = 0; a < N; ++a) {
+        const int *cb = p->cam_idx + p->pt_ptr[a];
+        const int d = (int)(p->pt_ptr[a + 1] - p->pt_ptr[a]);
+        for (int i = 0; i < d; ++i) {
+          if (cb[i] % n_thr != tid) continue;
+          long long *row = cnt.data() + pair_id(cb[i], cb[i]) - cb[i];  // row[l] = cnt[pair(k, l)]
+          for (int j = i; j < d; ++j) row[cb[j]]++;
+        }
       }
-    }
+    });
     long long T = 0, Tdiag = 0;
     for (int k = 0; k < m; ++k) Tdiag += cnt[pair_id(k, k)];
     for (long long q = 0; q < P; ++q) T += cnt[q];
@@ -1749,20 +1797,23 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     it_k.resize(T); it_l.resize(T); it_a.resize(T);
     {
       std::vector<long long> run(P, 0);
-      for (long long a = 0; a < N; ++a) {
-        const long long o0 = p->pt_ptr[a];
-        const int *cb = p->cam_idx + o0;
-        const int d = (int)(p->pt_ptr[a + 1] - o0);
-        for (int i = 0; i < d; ++i) {
-          const long long rowp = pair_id(cb[i], cb[i]) - cb[i];
-          for (int j = i; j < d; ++j) {
-            const long long q = rowp + cb[j], r = run[q]++;
-            const int sI = (int)(r % S[q]);
-            const long long pos = vp_off[vp_ptr[q] + sI] + r / S[q];
-            it_k[pos] = (int)(o0 + i); it_l[pos] = (int)(o0 + j); it_a[pos] = (int)a;
+      on_threads([&](int tid) {
+        for (long long a = 0; a < N; ++a) {
+          const long long o0 = p->pt_ptr[a];
+          const int *cb = p->cam_idx + o0;
+          const int d = (int)(p->pt_ptr[a + 1] - o0);
+          for (int i = 0; i < d; ++i) {
+            if (cb[i] % n_thr != tid) continue;
+            const long long rowp = pair_id(cb[i], cb[i]) - cb[i];
+            for (int j = i; j < d; ++j) {
+              const long long q = rowp + cb[j], r = run[q]++;
+              const int sI = (int)(r % S[q]);
+              const long long pos = vp_off[vp_ptr[q] + sI] + r / S[q];
+              it_k[pos] = (int)(o0 + i); it_l[pos] = (int)(o0 + j); it_a[pos] = (int)a;
+            }
           }
         }
-      }
+      });
     }
     // units: (pair, sub-list, point range), numbered pair-major (k_schur_reduce sums them in this order)
     unit_ptr.assign(P + 1, 0);
@@ -2218,6 +2269,56 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
   } else if (which == MVBA_BUF_TRIAL_CAM) {
     MVBA_HIP(d2h(h->d_cam15[1 - h->cur], sizeof(double) * cnt));
   }
+  return MVBA_OK;
+}
+
+int mvba_project(const double *X, int64_t n_points, const double *K, const double *R, const double *t, int32_t n_images,
+                 const int64_t *pt_ptr, const int32_t *cam_idx, int64_t n_obs, double *xy, int32_t device) {
+  if (!X || !K || !R || !t || !xy) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_points < 0 || n_images < 1 || n_obs < 0 || (pt_ptr && !cam_idx)) return fail(MVBA_ERR_BADARG, "bad sizes");
+  if (!pt_ptr && n_obs != n_points * (int64_t)n_images) return fail(MVBA_ERR_BADARG, "dense grid needs n_obs = n_points * n_images");
+  if (n_points >= (1LL << 31)) return fail(MVBA_ERR_BADARG, "n_points must be < 2^31");
+  if ((size_t)n_images * 12 * sizeof(double) > 160 * 1024 - 256) return fail(MVBA_ERR_BADARG, "too many cameras for the LDS camera table (max 1704)");
+  if (n_obs == 0) return MVBA_OK;
+  if (device >= 0) MVBA_HIP(hipSetDevice(device));
+  std::vector<int> obs_pt;
+  if (pt_ptr) {
+    if (pt_ptr[0] != 0 || pt_ptr[n_points] != n_obs) return fail(MVBA_ERR_BADARG, "pt_ptr does not span n_obs");
+    obs_pt.resize(n_obs);
+    for (int64_t a = 0; a < n_points; ++a)
+      for (int64_t o = pt_ptr[a]; o < pt_ptr[a + 1]; ++o) {
+        if (cam_idx[o] < 0 || cam_idx[o] >= n_images) return fail(MVBA_ERR_BADARG, "cam_idx out of range");
+        obs_pt[o] = (int)a;
+      }
+  }
+  double *dX = nullptr, *dK = nullptr, *dR = nullptr, *dt = nullptr;
+  double2 *dxy = nullptr;
+  int *dpt = nullptr, *dcam = nullptr;
+  auto cleanup = [&]() { for (void *q : {(void *)dX, (void *)dK, (void *)dR, (void *)dt, (void *)dxy, (void *)dpt, (void *)dcam}) if (q) hipFree(q); };
+#define PRJ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+  PRJ(hipMalloc((void **)&dX, sizeof(double) * 3 * std::max<int64_t>(n_points, 1)));
+  PRJ(hipMalloc((void **)&dK, sizeof(double) * 9 * n_images));
+  PRJ(hipMalloc((void **)&dR, sizeof(double) * 9 * n_images));
+  PRJ(hipMalloc((void **)&dt, sizeof(double) * 3 * n_images));
+  PRJ(hipMalloc((void **)&dxy, sizeof(double2) * n_obs));
+  PRJ(hipMemcpy(dX, X, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice));
+  PRJ(hipMemcpy(dK, K, sizeof(double) * 9 * n_images, hipMemcpyHostToDevice));
+  PRJ(hipMemcpy(dR, R, sizeof(double) * 9 * n_images, hipMemcpyHostToDevice));
+  PRJ(hipMemcpy(dt, t, sizeof(double) * 3 * n_images, hipMemcpyHostToDevice));
+  if (pt_ptr) {
+    PRJ(hipMalloc((void **)&dpt, sizeof(int) * n_obs));
+    PRJ(hipMalloc((void **)&dcam, sizeof(int) * n_obs));
+    PRJ(hipMemcpy(dpt, obs_pt.data(), sizeof(int) * n_obs, hipMemcpyHostToDevice));
+    PRJ(hipMemcpy(dcam, cam_idx, sizeof(int) * n_obs, hipMemcpyHostToDevice));
+  }
+  const int lds = (int)(sizeof(double) * 12 * n_images);
+  PRJ(hipFuncSetAttribute((const void *)k_project_obs, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n_obs + 255) / 256));
+  hipLaunchKernelGGL(k_project_obs, dim3(grid), dim3(256), lds, 0, (long long)n_obs, n_images, dX, dK, dR, dt, dpt, dcam, dxy);
+  PRJ(hipGetLastError());
+  PRJ(hipMemcpy(xy, dxy, sizeof(double2) * n_obs, hipMemcpyDeviceToHost));
+#undef PRJ
+  cleanup();
   return MVBA_OK;
 }
 

@@ -12,6 +12,17 @@
 //   K7c k_project  S = M^T W, i.e. S[i][row] = sum_c M[c][i] Wt[row][c]
 // sigma = sqrt(eig), M = eigenvectors of the r largest.  With fp64 accumulation the Gram
 // route loses nothing for fp32 data (eps32 >> eps64 * cond^2 for the leading triplets).
+// For fp64 DATA one Gram pass squares the condition number (a singular value 1e-7 below the
+// largest would only be good to 1e-2), so a second, preconditioned pass follows:
+//   K7d k_rotate   B = (Wt - 1 mu^T) V1            (V1 = eigenvectors of the first pass)
+//   K7a again      G2 = B^T B: nearly diagonal and GRADED -- its entries are formed from B's own
+//                  columns, i.e. accurate relative to the product of the two column norms, not to
+//                  sigma_1^2 -- and Jacobi with the relative threshold keeps that accuracy
+//   V = V1 V2, sigma = sqrt(eig G2): small singular values good to ~eps * sigma_1, like gesdd.
+// Centring subtracts the column means from the rows BEFORE they enter the Gram product
+// (G - s s^T / N cancels when |mean| >> spread).
+// A workspace handle (mvsvd_create / load / run / destroy) keeps the matrix, every buffer, the
+// stream and the events resident across calls; mvsvd_factorize is the one-shot form.
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -57,7 +68,7 @@ __device__ __forceinline__ void gram_store_partial(const svd_d4 *acc, int npairs
 constexpr int GRAM_ROWS = 4 * ROWS_PER_STEP;  // 128 rows per workgroup step
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, long long n_rows, int n,
-                                                    double *__restrict__ partial) {
+                                                    const double *__restrict__ mu, double *__restrict__ partial) {
   extern __shared__ double gram_lds_raw[];
   T *stage = reinterpret_cast<T *>(gram_lds_raw);  // GRAM_ROWS x n, row-major like Wt
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,8 +79,9 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
   svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
   int col[NT];
   bool cok[NT];
+  double muc[NT];  // column mean to subtract (0 without centring)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { cok[t] = GT * t + li < n; col[t] = min(GT * t + li, n - 1); }
+  for (int t = 0; t < NT; ++t) { cok[t] = GT * t + li < n; col[t] = min(GT * t + li, n - 1); muc[t] = mu ? mu[col[t]] : 0.0; }
   const long long total = n_rows * n;
   const int nvec = GRAM_ROWS * n / VEC;  // GRAM_ROWS * n is a multiple of 4
   for (long long r0 = (long long)blockIdx.y * GRAM_ROWS; r0 < n_rows; r0 += (long long)gridDim.y * GRAM_ROWS) {
@@ -94,13 +106,15 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
     }
     __syncthreads();
     const T *rows = stage + (size_t)(wave * ROWS_PER_STEP + lk) * n;
+    const long long row0 = r0 + wave * ROWS_PER_STEP + lk;
 #pragma unroll
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
       double v[NT];
+      const bool rok = row0 + 4 * g < n_rows;  // rows past the end are zeros in LDS: keep them zero when centring
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const double x = (double)rows[(size_t)(4 * g) * n + col[t]];
-        v[t] = cok[t] ? x : 0.0;
+        const double x = (double)rows[(size_t)(4 * g) * n + col[t]] - muc[t];
+        v[t] = (cok[t] && rok) ? x : 0.0;
       }
       int q = 0;
 #pragma unroll
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
 // larger n: blockIdx.x = one upper tile pair (the rows are re-read once per pair, from L2 / MALL)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, long long n_rows, int n, int n_tiles,
-                                                   int n_pairs, double *__restrict__ partial) {
+                                                   int n_pairs, const double *__restrict__ mu, double *__restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   int ti = 0, pr = blockIdx.x;
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, lon
   const int tj = ti + pr;
   const bool aok = GT * ti + li < n, bok = GT * tj + li < n;
   const int ca = min(GT * ti + li, n - 1), cb = min(GT * tj + li, n - 1);
+  const double mua = mu ? mu[ca] : 0.0, mub = mu ? mu[cb] : 0.0;
   svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
   const long long stride = (long long)gridDim.y * 4 * ROWS_PER_STEP;
   for (long long r0 = ((long long)blockIdx.y * 4 + wave) * ROWS_PER_STEP; r0 < n_rows; r0 += stride) {
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, lon
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
       const long long row = r0 + 4 * g + lk;
       const T *wr = Wt + min(row, n_rows - 1) * n;
-      const double xa = (double)wr[ca], xb = (double)wr[cb];
+      const double xa = (double)wr[ca] - mua, xb = (double)wr[cb] - mub;
       va[g] = (row < n_rows && aok) ? xa : 0.0;
       vb[g] = (row < n_rows && bok) ? xb : 0.0;
     }
@@ -175,14 +190,68 @@ __global__ __launch_bounds__(256) void k_colsum(const T *__restrict__ Wt, long l
   if (threadIdx.x == 0) atomicAdd(&colsum[c], red[0]);
 }
 
-// G (upper tiles) -> full symmetric, optionally centred: G - s s^T / N
-__global__ void k_gram_finish(double *__restrict__ G, const double *__restrict__ colsum, int n, long long n_rows,
-                              int center) {
+__global__ void k_mean_from_sum(const double *__restrict__ colsum, int n, long long n_rows, double *__restrict__ mu) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) mu[c] = colsum[c] / (double)n_rows;
+}
+
+// B[row][j] = sum_c (Wt[row][c] - mu[c]) V[c][j]   (fp64 out): the preconditioning rotation of the
+// second pass, and V1 V2 at the end (rows = n).  64 x 64 output tile per block, k in steps of 16
+// through LDS, 4 x 4 outputs per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rotate(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
+                                                const double *__restrict__ V, double *__restrict__ B) {
+  __shared__ double sW[64][17], sV[16][65];
+  const long long r0 = (long long)blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;  // thread -> rows tr + 16 u, columns tc + 16 v
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int r = e >> 4, k = e & 15;
+      const long long row = r0 + r;
+      sW[r][k] = (row < n_rows && k0 + k < n) ? (double)Wt[row * n + k0 + k] - (mu ? mu[k0 + k] : 0.0) : 0.0;
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int k = e >> 6, j = e & 63;
+      sV[k][j] = (k0 + k < n && j0 + j < n) ? V[(size_t)(k0 + k) * n + j0 + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = sW[tr + 16 * u][k];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = sV[k][tc + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long row = r0 + tr + 16 * u;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = j0 + tc + 16 * v;
+      if (row < n_rows && j < n) B[row * n + j] = acc[u][v];
+    }
+  }
+}
+
+// G (upper tiles) -> full symmetric
+__global__ void k_gram_finish(double *__restrict__ G, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j >= n || j < i) return;
   double v = G[(size_t)i * n + j];
   if (i / GT == j / GT && j > i) v = 0.5 * (v + G[(size_t)j * n + i]);  // diagonal tiles hold both halves
-  if (center) v -= colsum[i] * colsum[j] / (double)n_rows;
   G[(size_t)i * n + j] = v;
   G[(size_t)j * n + i] = v;
 }
@@ -419,75 +488,96 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
   }
 }
 
-template <typename T>
-int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M, T *sigma, T *S, T *means,
-              double *timings) {
+}  // namespace
+
+// Workspace: the resident matrix and every buffer a factorisation needs, allocated once.
+struct mvsvd_handle {
+  int device = 0, dtype = 0, n = 0;
+  long long max_rows = 0, n_rows = 0;
   hipStream_t st = nullptr;
-  MVBA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  T *dW = nullptr, *dS = nullptr;
-  double *dG = nullptr, *dV = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr;
+  hipEvent_t ev[6] = {};
+  void *dW = nullptr, *dS = nullptr;
+  double *dG = nullptr, *dV = nullptr, *dV1 = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr, *dB = nullptr;
   int *dsw = nullptr;
-  hipEvent_t ev[6];
-  for (auto &e : ev) hipEventCreate(&e);
-  int rc = MVBA_OK;
-  auto cleanup = [&]() {
-    for (void *p : {(void *)dW, (void *)dS, (void *)dG, (void *)dV, (void *)dsum, (void *)dMr, (void *)dmu, (void *)dsw, (void *)dpart})
-      if (p) hipFree(p);
-    for (auto &e : ev) hipEventDestroy(e);
-    hipStreamDestroy(st);
-  };
-#define SVD_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-  const size_t nn = (size_t)n * n;
-  SVD_HIP(hipMalloc((void **)&dW, sizeof(T) * (size_t)n_rows * n));
-  SVD_HIP(hipMalloc((void **)&dS, sizeof(T) * (size_t)n_rows * n_rank));
-  SVD_HIP(hipMalloc((void **)&dG, sizeof(double) * nn));
-  SVD_HIP(hipMalloc((void **)&dV, sizeof(double) * nn));
-  SVD_HIP(hipMalloc((void **)&dsum, sizeof(double) * n));
-  SVD_HIP(hipMalloc((void **)&dMr, sizeof(double) * (size_t)n * n_rank));
-  SVD_HIP(hipMalloc((void **)&dmu, sizeof(double) * n));
-  SVD_HIP(hipMalloc((void **)&dsw, sizeof(int)));
-  const int n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
-  const bool fused = n_tiles <= 2;
-  const int chunks = (int)std::max<long long>(1, std::min<long long>((n_rows + 4 * ROWS_PER_STEP - 1) / (4 * ROWS_PER_STEP),
-                                                                    fused ? 2048 : std::max(8, 4096 / n_pairs)));
-  SVD_HIP(hipMalloc((void **)&dpart, sizeof(double) * (size_t)chunks * n_pairs * 256));
-  hipEventRecord(ev[0], st);
-  SVD_HIP(hipMemcpyAsync(dW, Wt, sizeof(T) * (size_t)n_rows * n, hipMemcpyHostToDevice, st));
-  hipEventRecord(ev[1], st);
-  SVD_HIP(hipMemsetAsync(dG, 0, sizeof(double) * nn, st));
-  SVD_HIP(hipMemsetAsync(dsum, 0, sizeof(double) * n, st));
+  int chunks = 1, rank_cap = 0;
+  double h2d_ms = 0.0;
+  bool loaded = false;
+};
+
+namespace {
+
+template <typename T>
+void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) {
+  const int n = h->n, n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
+  hipMemsetAsync(h->dG, 0, sizeof(double) * (size_t)n * n, h->st);
   if (n_tiles == 1)
-    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, st, dW, n_rows, n, dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
   else if (n_tiles == 2)
-    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, st, dW, n_rows, n, dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
   else
-    hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, st, dW, n_rows, n, n_tiles, n_pairs, dpart);
-  hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, std::min(chunks, 32)), dim3(256), 0, st, dpart, chunks, n, n_tiles, n_pairs, dG);
-  if (center) {
-    const int cy = (int)std::max<long long>(1, std::min<long long>(256, n_rows / 4096));
-    hipLaunchKernelGGL(k_colsum<T>, dim3(n, cy), dim3(256), 0, st, dW, n_rows, n, dsum);
-  }
-  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, st, dG, dsum, n, n_rows, center);
-  hipEventRecord(ev[2], st);
-  const int np = (n + 1) & ~1;
-  const size_t jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
+    hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, h->st, W, h->n_rows, n, n_tiles, n_pairs, mu, h->dpart);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, std::min(chunks, 32)), dim3(256), 0, h->st, h->dpart, chunks, n, n_tiles, n_pairs, h->dG);
+  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dG, n);
+}
+
+void launch_jacobi(mvsvd_handle *h, double *dVout) {
+  const int n = h->n, np = (n + 1) & ~1;
+  const size_t nn = (size_t)n * n, jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
   if (n <= JW)
-    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, st, dG, dV, n, 60, 1e-15, dsw);
+    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
   else if (n <= 64)
-    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, st, dG, dV, n, 60, 1e-15, dsw);
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
   else
-    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, st, dG, dV, n, 60, 1e-15, dsw);
-  hipEventRecord(ev[3], st);
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
+}
+
+int chunks_for(long long n_rows, int n) {
+  const int n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
+  return (int)std::max<long long>(1, std::min<long long>((n_rows + 4 * ROWS_PER_STEP - 1) / (4 * ROWS_PER_STEP),
+                                                         n_tiles <= 2 ? 2048 : std::max(8, 4096 / n_pairs)));
+}
+
+template <typename T>
+int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means, double *timings) {
+  const int n = h->n;
+  const long long n_rows = h->n_rows;
+  const size_t nn = (size_t)n * n;
+  hipStream_t st = h->st;
+  const T *dW = (const T *)h->dW;
+  const int chunks = chunks_for(n_rows, n);
+  const bool refine = sizeof(T) == 8;  // fp64 data: second, preconditioned pass (see the file header)
+  hipEventRecord(h->ev[1], st);
+  const double *mu = nullptr;
+  if (center) {  // column means first: the rows are centred as they enter the products
+    MVBA_HIP(hipMemsetAsync(h->dsum, 0, sizeof(double) * n, st));
+    const int cy = (int)std::max<long long>(1, std::min<long long>(256, n_rows / 4096));
+    hipLaunchKernelGGL(k_colsum<T>, dim3(n, cy), dim3(256), 0, st, dW, n_rows, n, h->dsum);
+    hipLaunchKernelGGL(k_mean_from_sum, dim3((n + 255) / 256), dim3(256), 0, st, h->dsum, n, n_rows, h->dmu);
+    mu = h->dmu;
+  }
+  launch_gram<T>(h, dW, mu, chunks);
+  hipEventRecord(h->ev[2], st);
+  launch_jacobi(h, refine ? h->dV1 : h->dV);
+  hipEventRecord(h->ev[3], st);
+  if (refine) {
+    if (!h->dB) MVBA_HIP(hipMalloc((void **)&h->dB, sizeof(double) * (size_t)h->max_rows * n));
+    hipLaunchKernelGGL(k_rotate<T>, dim3((unsigned)((n_rows + 63) / 64), (n + 63) / 64), dim3(256), 0, st, dW, n_rows, n, mu, h->dV1, h->dB);
+    launch_gram<double>(h, h->dB, nullptr, chunks);
+    launch_jacobi(h, h->dMr /* V2, n x n: dMr is sized for it */);
+    // V = V1 V2
+    hipLaunchKernelGGL(k_rotate<double>, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, st, h->dV1, (long long)n, n, (const double *)nullptr,
+                       h->dMr, h->dV);
+  }
   // eigenvalues -> host, sort, build the rank-r basis with a deterministic sign
-  std::vector<double> hG(nn), hV(nn), hsum(n);
-  SVD_HIP(hipMemcpyAsync(hG.data(), dG, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
-  SVD_HIP(hipMemcpyAsync(hV.data(), dV, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
-  SVD_HIP(hipMemcpyAsync(hsum.data(), dsum, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  SVD_HIP(hipStreamSynchronize(st));
+  std::vector<double> hG(nn), hV(nn), hmu(n, 0.0);
+  MVBA_HIP(hipMemcpyAsync(hG.data(), h->dG, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipMemcpyAsync(hV.data(), h->dV, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+  if (center) MVBA_HIP(hipMemcpyAsync(hmu.data(), h->dmu, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::sort(order.begin(), order.end(), [&](int a, int b) { return hG[(size_t)a * n + a] > hG[(size_t)b * n + b]; });
-  std::vector<double> Mr((size_t)n * n_rank), mu(n, 0.0);
+  std::vector<double> Mr((size_t)n * n_rank);
   for (int i = 0; i < n; ++i) sigma[i] = (T)std::sqrt(std::max(0.0, hG[(size_t)order[i] * n + order[i]]));
   for (int i = 0; i < n_rank; ++i) {
     const int col = order[i];
@@ -500,53 +590,132 @@ int factorize(const T *Wt, long long n_rows, int n, int n_rank, int center, T *M
       M[(size_t)c * n_rank + i] = (T)Mr[(size_t)c * n_rank + i];
     }
   }
-  if (center)
-    for (int c = 0; c < n; ++c) mu[c] = hsum[c] / (double)n_rows;
   if (means)
-    for (int c = 0; c < n; ++c) means[c] = (T)mu[c];
-  SVD_HIP(hipMemcpyAsync(dMr, Mr.data(), sizeof(double) * Mr.size(), hipMemcpyHostToDevice, st));
-  SVD_HIP(hipMemcpyAsync(dmu, mu.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-  hipEventRecord(ev[4], st);
+    for (int c = 0; c < n; ++c) means[c] = (T)hmu[c];
+  // S = M^T W in groups of (up to) 4 basis vectors per pass over W
+  if (n_rank > h->rank_cap) {
+    if (h->dS) MVBA_HIP(hipFree(h->dS));
+    h->dS = nullptr;
+    MVBA_HIP(hipMalloc(&h->dS, sizeof(T) * (size_t)h->max_rows * n_rank));
+    h->rank_cap = n_rank;
+  }
+  hipEventRecord(h->ev[4], st);
   const int pgrid = (int)std::max<long long>(1, std::min<long long>(4096, (n_rows + 255) / 256));
   const int ldt = std::min(n, PC) | 1;
   const size_t plds = sizeof(double) * (5 * (size_t)n) + sizeof(T) * 4 * 64 * (size_t)ldt + 16;
-  hipLaunchKernelGGL(k_project<T>, dim3(pgrid), dim3(256), plds, st, dW, n_rows, n, n_rank, dMr,
-                     center ? dmu : nullptr, dS);
-  hipEventRecord(ev[5], st);
-  SVD_HIP(hipMemcpyAsync(S, dS, sizeof(T) * (size_t)n_rows * n_rank, hipMemcpyDeviceToHost, st));
-  SVD_HIP(hipStreamSynchronize(st));
-  SVD_HIP(hipGetLastError());
+  std::vector<double> Mg((size_t)n * 4);
+  for (int g0 = 0; g0 < n_rank; g0 += 4) {
+    const int rg = std::min(4, n_rank - g0);
+    for (int c = 0; c < n; ++c)
+      for (int i = 0; i < rg; ++i) Mg[(size_t)c * rg + i] = Mr[(size_t)c * n_rank + g0 + i];
+    MVBA_HIP(hipMemcpyAsync(h->dMr, Mg.data(), sizeof(double) * (size_t)n * rg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_project<T>, dim3(pgrid), dim3(256), plds, st, dW, n_rows, n, rg, h->dMr, mu, (T *)h->dS + (size_t)g0 * n_rows);
+    MVBA_HIP(hipStreamSynchronize(st));  // Mg is reused by the next group
+  }
+  hipEventRecord(h->ev[5], st);
+  MVBA_HIP(hipMemcpyAsync(S, h->dS, sizeof(T) * (size_t)n_rows * n_rank, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
+  MVBA_HIP(hipGetLastError());
   if (timings) {
     float ms;
-    hipEventElapsedTime(&ms, ev[0], ev[1]); timings[0] = ms;  // H2D
-    hipEventElapsedTime(&ms, ev[1], ev[2]); timings[1] = ms;  // Gram (+sums, finish)
-    hipEventElapsedTime(&ms, ev[2], ev[3]); timings[2] = ms;  // Jacobi
-    hipEventElapsedTime(&ms, ev[4], ev[5]); timings[3] = ms;  // projection
+    timings[0] = h->h2d_ms;                                                   // H2D of the last load
+    hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); timings[1] = ms;            // means + Gram
+    hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); timings[2] = ms;            // Jacobi (first pass)
+    hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); timings[3] = ms;            // projection
     int sw = 0;
-    hipMemcpy(&sw, dsw, sizeof(int), hipMemcpyDeviceToHost);
-    timings[4] = sw;  // Jacobi sweeps
+    hipMemcpy(&sw, h->dsw, sizeof(int), hipMemcpyDeviceToHost);
+    timings[4] = sw;                                                          // Jacobi sweeps (last pass)
+    if (refine) { hipEventElapsedTime(&ms, h->ev[3], h->ev[4]); timings[5] = ms; }  // refinement pass (rotate, Gram, Jacobi, V1 V2)
+    else timings[5] = 0.0;
   }
-#undef SVD_HIP
-  cleanup();
-  return rc;
+  return MVBA_OK;
 }
 
 }  // namespace
 
-extern "C" int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank,
-                               int32_t center, void *M, void *sigma, void *S, void *means, double *timings_ms,
-                               int32_t device) {
-  if (!Wt || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
-  if (n_rows < 1 || n_cols < 1 || n_rank < 1 || n_rank > 4 || n_rank > n_cols || n_cols > 2048)
-    return fail(MVBA_ERR_BADARG, "need n_rows >= 1, 1 <= n_rank <= min(4, n_cols), n_cols <= 2048");
+extern "C" {
+
+int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device, mvsvd_handle **out) {
+  if (!out) return fail(MVBA_ERR_BADARG, "null argument");
+  if (max_rows < 1 || n_cols < 1 || n_cols > 2048)
+    return fail(MVBA_ERR_BADARG, "need max_rows >= 1 and 1 <= n_cols <= 2048 (the n_cols x n_cols eigenproblem runs in one workgroup)");
   if (dtype != 0 && dtype != 1) return fail(MVBA_ERR_BADARG, "dtype must be 0 (float32) or 1 (float64)");
   if (device >= 0) MVBA_HIP(hipSetDevice(device));
-  MVBA_HIP(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  MVBA_HIP(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-  MVBA_HIP(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-  if (dtype == 0)
-    return factorize<float>((const float *)Wt, n_rows, n_cols, n_rank, center, (float *)M, (float *)sigma, (float *)S,
-                            (float *)means, timings_ms);
-  return factorize<double>((const double *)Wt, n_rows, n_cols, n_rank, center, (double *)M, (double *)sigma,
-                           (double *)S, (double *)means, timings_ms);
+  mvsvd_handle *h = new mvsvd_handle();
+  MVBA_HIP(hipGetDevice(&h->device));
+  h->dtype = dtype; h->n = n_cols; h->max_rows = max_rows;
+  const size_t el = dtype ? 8 : 4, nn = (size_t)n_cols * n_cols;
+  const int n_tiles = (n_cols + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
+  h->chunks = chunks_for(max_rows, n_cols);
+#define SVD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvsvd_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+  SVD_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  for (auto &e : h->ev) SVD_TRY(hipEventCreate(&e));
+  SVD_TRY(hipMalloc(&h->dW, el * (size_t)max_rows * n_cols));
+  SVD_TRY(hipMalloc((void **)&h->dG, sizeof(double) * nn));
+  SVD_TRY(hipMalloc((void **)&h->dV, sizeof(double) * nn));
+  SVD_TRY(hipMalloc((void **)&h->dV1, sizeof(double) * nn));
+  SVD_TRY(hipMalloc((void **)&h->dMr, sizeof(double) * std::max(nn, (size_t)4 * n_cols)));
+  SVD_TRY(hipMalloc((void **)&h->dsum, sizeof(double) * n_cols));
+  SVD_TRY(hipMalloc((void **)&h->dmu, sizeof(double) * n_cols));
+  SVD_TRY(hipMalloc((void **)&h->dsw, sizeof(int)));
+  SVD_TRY(hipMalloc((void **)&h->dpart, sizeof(double) * (size_t)h->chunks * n_pairs * 256));
+  SVD_TRY(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  SVD_TRY(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+  SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+#undef SVD_TRY
+  *out = h;
+  return MVBA_OK;
 }
+
+void mvsvd_destroy(mvsvd_handle *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->st) hipStreamSynchronize(h->st);
+  for (void *p : {h->dW, h->dS, (void *)h->dG, (void *)h->dV, (void *)h->dV1, (void *)h->dsum, (void *)h->dMr, (void *)h->dmu,
+                  (void *)h->dsw, (void *)h->dpart, (void *)h->dB})
+    if (p) hipFree(p);
+  for (auto &e : h->ev)
+    if (e) hipEventDestroy(e);
+  if (h->st) hipStreamDestroy(h->st);
+  delete h;
+}
+
+int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows) {
+  if (!h || !Wt) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_rows < 1 || n_rows > h->max_rows) return fail(MVBA_ERR_BADARG, "n_rows outside the workspace (1 .. max_rows)");
+  MVBA_HIP(hipSetDevice(h->device));
+  hipEventRecord(h->ev[0], h->st);
+  MVBA_HIP(hipMemcpyAsync(h->dW, Wt, (h->dtype ? 8 : 4) * (size_t)n_rows * h->n, hipMemcpyHostToDevice, h->st));
+  hipEventRecord(h->ev[1], h->st);
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+  h->h2d_ms = ms;
+  h->n_rows = n_rows;
+  h->loaded = true;
+  return MVBA_OK;
+}
+
+int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *sigma, void *S, void *means, double *timings_ms) {
+  if (!h || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->loaded) return fail(MVBA_ERR_STATE, "mvsvd_run before mvsvd_load");
+  if (n_rank < 1 || n_rank > h->n) return fail(MVBA_ERR_BADARG, "need 1 <= n_rank <= n_cols");
+  MVBA_HIP(hipSetDevice(h->device));
+  if (h->dtype == 0) return run<float>(h, n_rank, center, (float *)M, (float *)sigma, (float *)S, (float *)means, timings_ms);
+  return run<double>(h, n_rank, center, (double *)M, (double *)sigma, (double *)S, (double *)means, timings_ms);
+}
+
+int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank, int32_t center, void *M,
+                    void *sigma, void *S, void *means, double *timings_ms, int32_t device) {
+  if (!Wt || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_rows < 1 || n_cols < 1 || n_rank < 1 || n_rank > n_cols) return fail(MVBA_ERR_BADARG, "need n_rows >= 1, 1 <= n_rank <= n_cols");
+  mvsvd_handle *h = nullptr;
+  int rc = mvsvd_create(n_rows, n_cols, dtype, device, &h);
+  if (rc) return rc;
+  rc = mvsvd_load(h, Wt, n_rows);
+  if (!rc) rc = mvsvd_run(h, n_rank, center, M, sigma, S, means, timings_ms);
+  mvsvd_destroy(h);
+  return rc;
+}
+
+}  // extern "C"

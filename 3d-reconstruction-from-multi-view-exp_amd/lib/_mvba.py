@@ -58,8 +58,14 @@ SIGNATURES = {
     "mvba_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mvba_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]),
     "mvba_host_obs_math": (C.c_int, [_dp, _dp, _dp, C.c_double, _dp]),
+    "mvba_project": (C.c_int, [_dp, C.c_int64, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                               C.c_int64, _dp, C.c_int32]),
     "mvsvd_factorize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int32]),
+    "mvsvd_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "mvsvd_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mvsvd_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
+    "mvsvd_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None
@@ -215,12 +221,83 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def project(X, K, R, t, pt_ptr=None, cam_idx=None, device=-1):
+    """Device pinhole projection (mvba_project).  With an observation list (pt_ptr, cam_idx):
+    (n_obs, 2); without: the dense grid (N, m, 2).  No CPU fallback."""
+    lib = load_library()
+    if device_count() < 1:
+        raise RuntimeError("libmvba: no HIP device visible; mvba_project has no CPU fallback")
+    X, K, R, t = (_as(v, np.float64) for v in (X, K, R, t))
+    n, m = X.shape[0], K.shape[0]
+    assert X.shape == (n, 3) and K.shape == (m, 3, 3) and R.shape == (m, 3, 3) and t.shape == (m, 3)
+    if pt_ptr is None:
+        out = np.empty((n, m, 2))
+        rc = lib.mvba_project(_ptr(X), n, _ptr(K), _ptr(R), _ptr(t), m, None, None, n * m, _ptr(out), int(device))
+    else:
+        pt_ptr, cam_idx = _as(pt_ptr, np.int64), _as(cam_idx, np.int32)
+        out = np.empty((cam_idx.shape[0], 2))
+        rc = lib.mvba_project(_ptr(X), n, _ptr(K), _ptr(R), _ptr(t), m, pt_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                              cam_idx.ctypes.data_as(C.POINTER(C.c_int32)), cam_idx.shape[0], _ptr(out), int(device))
+    raise_for(rc, lib)
+    return out
+
+
 def host_obs_math(X3, cam15, xy2, f0):
     lib = load_library()
     out = np.empty(26)
     X3, cam15, xy2 = _as(X3, np.float64), _as(cam15, np.float64), _as(xy2, np.float64)
     raise_for(lib.mvba_host_obs_math(_ptr(X3), _ptr(cam15), _ptr(xy2), float(f0), _ptr(out)), lib)
     return out[:2], out[2:8].reshape(2, 3), out[8:].reshape(2, 9)
+
+
+def _tm(tm):
+    return {"h2d_ms": tm[0], "gram_ms": tm[1], "jacobi_ms": tm[2], "project_ms": tm[3], "sweeps": int(tm[4]),
+            "refine_ms": tm[5]}
+
+
+class SvdWorkspace:
+    """Device-resident factorization workspace (mvsvd_create / load / run / destroy): buffers,
+    stream and events are made once; ``load`` is the only host-to-device copy; ``run`` may be
+    called any number of times on the resident matrix."""
+
+    def __init__(self, max_rows, n_cols, dtype, device=-1):
+        self.lib = load_library()
+        if device_count() < 1:
+            raise RuntimeError("libmvba: no HIP device visible; the SVD kernel has no CPU fallback")
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise ValueError("dtype must be float32 or float64")
+        self.max_rows, self.n_cols, self.n_rows = int(max_rows), int(n_cols), 0
+        h = C.c_void_p()
+        raise_for(self.lib.mvsvd_create(self.max_rows, self.n_cols, 0 if self.dtype == np.float32 else 1, int(device),
+                                        C.byref(h)), self.lib)
+        self._h = h
+
+    def load(self, Wt):
+        Wt = np.ascontiguousarray(Wt, dtype=self.dtype)
+        if Wt.ndim != 2 or Wt.shape[1] != self.n_cols:
+            raise ValueError("Wt must be (n_rows, n_cols) of the workspace")
+        raise_for(self.lib.mvsvd_load(self._h, Wt.ctypes.data, Wt.shape[0]), self.lib)
+        self.n_rows = Wt.shape[0]
+        return self
+
+    def run(self, n_rank, center=False):
+        """M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings."""
+        M = np.empty((self.n_cols, n_rank), self.dtype)
+        sigma = np.empty(self.n_cols, self.dtype)
+        S = np.empty((n_rank, self.n_rows), self.dtype)
+        means = np.zeros(self.n_cols, self.dtype)
+        tm = np.zeros(6)
+        raise_for(self.lib.mvsvd_run(self._h, int(n_rank), int(bool(center)), M.ctypes.data, sigma.ctypes.data,
+                                     S.ctypes.data, means.ctypes.data, _ptr(tm)), self.lib)
+        return M, sigma, S, means, _tm(tm)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mvsvd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def svd_factorize(Wt, n_rank, center=False, device=-1):
@@ -237,10 +314,9 @@ def svd_factorize(Wt, n_rank, center=False, device=-1):
     sigma = np.empty(n_cols, Wt.dtype)
     S = np.empty((n_rank, n_rows), Wt.dtype)
     means = np.zeros(n_cols, Wt.dtype)
-    tm = np.zeros(5)
+    tm = np.zeros(6)
     rc = lib.mvsvd_factorize(Wt.ctypes.data, n_rows, n_cols, 0 if Wt.dtype == np.float32 else 1, int(n_rank),
                              int(bool(center)), M.ctypes.data, sigma.ctypes.data, S.ctypes.data, means.ctypes.data,
                              _ptr(tm), int(device))
     raise_for(rc, lib)
-    return M, sigma, S, means, {"h2d_ms": tm[0], "gram_ms": tm[1], "jacobi_ms": tm[2], "project_ms": tm[3],
-                                "sweeps": int(tm[4])}
+    return M, sigma, S, means, _tm(tm)

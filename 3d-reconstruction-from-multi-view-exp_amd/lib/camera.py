@@ -43,6 +43,15 @@ def calc_projected_points(X, K, R, t):
     return [Camera(Rk, tk, Kk).project_points(X, method="perspective") for Rk, tk, Kk in zip(R, t, K)]
 
 
+def calc_projected_points_gpu(X, K, R, t, device=-1):
+    """``calc_projected_points`` on the MI355X (``mvba_project``, csrc/mvba.hip): same list of (N,2)
+    arrays, one launch for the whole (point, camera) grid."""
+    from ._mvba import project
+
+    x = project(X, K, R, t, device=device)  # (N, m, 2)
+    return [np.ascontiguousarray(x[:, k]) for k in range(x.shape[1])]
+
+
 def get_camera_parames(camera_list):
     K, R, t = zip(*(c.get_parameters() for c in camera_list))
     return np.stack(K), np.stack(R), np.stack(t)

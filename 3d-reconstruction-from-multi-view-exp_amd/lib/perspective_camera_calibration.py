@@ -27,8 +27,32 @@ from .factorization import factorization_method
 from .utils import unit_vec
 
 
+class _GpuSvd4:
+    """Wt (N, 3m) -> U[:, :4] (3m,4), sigma (>=4,), diag(sigma[:4]) Vt[:4] (4,N) on a device workspace
+    that lives as long as the depth loop (50-200 calls): only the matrix itself crosses PCIe."""
+
+    def __init__(self):
+        self._ws = None
+
+    def __call__(self, Wt: npt.NDArray):
+        from ._mvba import SvdWorkspace
+
+        Wt = np.ascontiguousarray(Wt)
+        if self._ws is None or self._ws.max_rows < Wt.shape[0] or self._ws.n_cols != Wt.shape[1] or self._ws.dtype != Wt.dtype:
+            if self._ws is not None:
+                self._ws.close()
+            self._ws = SvdWorkspace(Wt.shape[0], Wt.shape[1], Wt.dtype if Wt.dtype in (np.float32, np.float64) else np.float64)
+        M, sigma, S, _mu, _tm = self._ws.load(Wt).run(4)
+        return M, sigma, S
+
+    def close(self):
+        if self._ws is not None:
+            self._ws.close()
+            self._ws = None
+
+
 def _gpu_svd4(Wt: npt.NDArray):
-    """Wt (N, 3m) -> U[:, :4] (3m,4), sigma (>=4,), diag(sigma[:4]) Vt[:4] (4,N)."""
+    """One-shot form of ``_GpuSvd4`` (kept for callers that factorize once)."""
     from ._mvba import svd_factorize
 
     M, sigma, S, _mu, _tm = svd_factorize(Wt, 4)
@@ -58,13 +82,14 @@ def _dominant_left_vector(C):
     return xi / np.linalg.norm(xi, axis=-1, keepdims=True)
 
 
-def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 200, svd=_gpu_svd4):
+def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 200, svd=None):
     """Primary method (:61-144): alternate a rank-4 fit of the column-normalised measurement
     matrix with per-point depth updates."""
     n_points, n_images = x.shape[:2]
     z = np.ones((n_points, n_images))
     x_norm = np.linalg.norm(x, axis=2)
     count = 0
+    svd = svd or _GpuSvd4()
     while True:
         W = x * z[..., None]
         W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]  # every point's 3m-column to unit length
@@ -85,18 +110,21 @@ def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 2
     return z
 
 
-def _compute_projective_depth_dual_method(x, f0, tolerance, max_iter: int = 50, svd=_gpu_svd4):
+def _compute_projective_depth_dual_method(x, f0, tolerance, max_iter: int = 50, svd=None):
     """Dual method (:147-235): rows (images) normalised, per-image depth updates."""
     n_points, n_images = x.shape[:2]
     z = np.ones((n_points, n_images))
     x_norm = np.linalg.norm(x, axis=2)          # (N, m)
     x_hat = x / x_norm[..., None]
     count = 0
+    svd = svd or _GpuSvd4()
     while True:
         W = x * z[..., None]
         # each image's 3 x N block divided by its SQUARED Frobenius norm (:170-172)
         W = W / (W**2).sum(axis=(0, 2))[None, :, None]
         M, sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
+        if not (sigma[:4] > 0).all():           # rank-deficient measurement matrix: no 4th right singular vector
+            raise np.linalg.LinAlgError("measurement matrix has rank < 4")
         V4 = (S / sigma[:4, None]).T             # (N, 4) right singular vectors
         # B_k = (V4 V4^T) o (x_k x_k^T) / (|x||x|^T) = Z_k Z_k^T,  Z_k[a] = V4[a] (x) x_hat[a, k]
         Z = np.einsum("ai,akc->kaic", V4, x_hat).reshape(n_images, n_points, 12)

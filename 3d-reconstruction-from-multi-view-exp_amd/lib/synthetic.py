@@ -112,7 +112,26 @@ def make_cameras(n_images, seed=0, perturb_seed=2, sigma=0.01):
     return K, R, pos, K0, R0, t0
 
 
-def _chunk_points(cid, n_images, vis_p, seed, vis_seed, perturb_seed, noise, sigma, cams):
+def _project(X, K, R, t, pt, cam, how):
+    """Exact projections of the chunk's observations: on the MI355X (``mvba_project``) when a device
+    is there, else host NumPy.  The two agree to ~1e-15 (tests/test_gpu_callers.py)."""
+    if how == "auto":
+        from . import _mvba
+
+        try:
+            how = "gpu" if _mvba.device_count() > 0 else "numpy"
+        except Exception:  # noqa: BLE001  (library not built: CPU-only test environments)
+            how = "numpy"
+    if how == "gpu":
+        from . import _mvba
+
+        pt_ptr = np.zeros(len(X) + 1, np.int64)
+        np.cumsum(np.bincount(pt, minlength=len(X)), out=pt_ptr[1:])
+        return _mvba.project(X, K, R, t, pt_ptr, cam)
+    return project_obs(X, K[:, 0, 0], K[:, :2, 2], t, R, 1.0, pt, cam)
+
+
+def _chunk_points(cid, n_images, vis_p, seed, vis_seed, perturb_seed, noise, sigma, cams, project="auto"):
     """Everything for global points [cid*CHUNK, (cid+1)*CHUNK)."""
     K, R, t = cams
     rng = np.random.default_rng([seed, 1, cid])
@@ -144,22 +163,21 @@ def _chunk_points(cid, n_images, vis_p, seed, vis_seed, perturb_seed, noise, sig
             cam = np.concatenate([cam[keep]] + add_cam)
             order = np.lexsort((cam, pt))
             pt, cam = pt[order], cam[order]
-    f = K[:, 0, 0]
-    u = K[:, :2, 2]
-    xy = project_obs(X, f, u, t, R, 1.0, pt, cam) + vr.normal(0, noise, (len(pt), 2))
+    xy = _project(X, K, R, t, pt, cam.astype(np.int32), project) + vr.normal(0, noise, (len(pt), 2))
     X0 = X + np.random.default_rng([perturb_seed, 1, cid]).normal(0, sigma, X.shape)
     return X, X0, pt, cam.astype(np.int32), xy
 
 
 def make_scene(n_points, n_images, vis_p=1.0, seed=0, vis_seed=1, perturb_seed=2, noise=1e-3, sigma=0.01,
-               point_range=None) -> Scene:
-    """Scene slice for global points ``point_range = (lo, hi)`` (default: all)."""
+               point_range=None, project="auto") -> Scene:
+    """Scene slice for global points ``point_range = (lo, hi)`` (default: all).  ``project``:
+    "gpu" (mvba_project), "numpy", or "auto" (the device when one is visible)."""
     lo, hi = (0, n_points) if point_range is None else point_range
     K, R, t, K0, R0, t0 = make_cameras(n_images, seed, perturb_seed, sigma)
     Xs, X0s, pts, cams, xys = [], [], [], [], []
     base = 0
     for cid in range(lo // CHUNK, (max(hi, lo + 1) - 1) // CHUNK + 1):
-        X, X0, pt, cam, xy = _chunk_points(cid, n_images, vis_p, seed, vis_seed, perturb_seed, noise, sigma, (K, R, t))
+        X, X0, pt, cam, xy = _chunk_points(cid, n_images, vis_p, seed, vis_seed, perturb_seed, noise, sigma, (K, R, t), project)
         g0 = cid * CHUNK
         a, b = max(lo, g0) - g0, min(hi, g0 + CHUNK) - g0
         sel = (pt >= a) & (pt < b)

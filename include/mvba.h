@@ -132,6 +132,15 @@ enum {
 };
 int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity, int64_t *n);
 
+/* Pinhole projection of an observation list on the device: xy[o] = inhomogeneous
+ * K_k [R_k^T | -R_k^T t_k] [X_a; 1] (ref lib/camera.py:13-14, :30-34, :74-81 -- the scene side of
+ * BA: synthetic observations before it, re-projection after it).  K, R [n_images][3][3] row-major
+ * (R: columns = camera axes), t [n_images][3].  pt_ptr / cam_idx as in mvba_problem; pt_ptr == NULL
+ * means the dense grid (n_obs = n_points * n_images, observation = point * n_images + camera: the
+ * reference's calc_projected_points, transposed).  xy [n_obs][2] is written. */
+int mvba_project(const double *X, int64_t n_points, const double *K, const double *R, const double *t, int32_t n_images,
+                 const int64_t *pt_ptr, const int32_t *cam_idx, int64_t n_obs, double *xy, int32_t device);
+
 /* Host-only check of the per-observation math the kernels use (no GPU needed):
  * cam15 = f,u,v,t[3],R[9]; out = e[2], JX[6], JC[18].                          */
 int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2, double f0,
@@ -149,10 +158,27 @@ int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2,
  * descending), S [n_rank][n_rows] (= diag(sigma[:r]) Vt[:r] = M^T W).  Thin: Vt is
  * never formed.  Sign convention: the largest-magnitude component of every column
  * of M is positive (LAPACK's signs are not a rule one can restate).
- * timings_ms (may be NULL) [5]: H2D, Gram, Jacobi, projection (device ms), sweeps. */
+ * n_rank: any 1 .. n_cols (the projection runs in groups of 4 basis vectors); n_cols <= 2048 (the
+ * n_cols x n_cols eigenproblem is solved by one workgroup).
+ * Accuracy: float32 data -> one Gram pass accumulated in fp64 (nothing is lost: eps32 >> eps64 *
+ * cond^2); float64 data -> a second, preconditioned pass so that small singular values are good to
+ * ~eps64 * sigma_1 like LAPACK's gesdd, not to sqrt(eps64) * sigma_1 (see csrc/mvsvd.hip).
+ * timings_ms (may be NULL) [6]: H2D, means + Gram, Jacobi, projection (device ms), sweeps,
+ * refinement pass (0 for float32). */
 int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank,
                     int32_t center, void *M, void *sigma, void *S, void *means, double *timings_ms,
                     int32_t device);
+
+/* Workspace form for repeated factorizations (the projective-depth loops call the SVD 50-200
+ * times, ref perspective_camera_calibration.py:61-144, :147-235): create once (device buffers
+ * for up to max_rows x n_cols, stream, events), load a matrix (the only host-to-device copy),
+ * run any number of factorizations on the resident matrix (different n_rank / center), destroy. */
+typedef struct mvsvd_handle mvsvd_handle;
+int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device, mvsvd_handle **out);
+int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows);
+int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *sigma, void *S, void *means,
+              double *timings_ms);
+void mvsvd_destroy(mvsvd_handle *h);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,40 @@ def test_affine_driver_runs(golden, capsys):
     assert len(E) >= 2 and E[-1] < 0.05 * E[0]
     # either the reference's minimum (0.2179) or the mirror-parity one (0.0993): SURVEY §7 hard part 4
     assert min(abs(E[-1] - 0.21790752620130377), abs(E[-1] - 0.0993)) < 5e-3, E[-1]
+
+
+def test_device_projection_matches_lib_camera(golden):
+    """mvba_project (csrc/mvba.hip k_project_obs) vs the host camera model on the reference's own
+    default scene: the fixture's noise-free projections x_clean were produced by the reference's
+    calc_projected_points (ref lib/camera.py:74-81); dense grid and observation-list forms."""
+    from lib import _mvba
+    from lib.camera import calc_projected_points, calc_projected_points_gpu
+    from lib.synthetic import make_scene
+
+    d = golden("euclid_default")
+    X, K, R, t = d["X_gt"], d["K_gt"], d["R_gt"], d["t_gt"]
+    x_gpu = calc_projected_points_gpu(X, K, R, t)
+    x_host = calc_projected_points(X, K, R, t)
+    assert len(x_gpu) == len(x_host) == 10
+    for k in range(10):
+        np.testing.assert_allclose(x_gpu[k], d["x_clean"][k], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(x_gpu[k], x_host[k], rtol=0, atol=1e-13)
+    # observation list: every third (point, camera) pair, non-trivial intrinsics
+    rng = np.random.default_rng(5)
+    K2 = K.copy()
+    K2[:, 0, 0] = K2[:, 1, 1] = 1.0 + 0.1 * rng.uniform(size=10)
+    K2[:, :2, 2] = 0.05 * rng.normal(size=(10, 2))
+    vis = rng.uniform(size=(200, 10)) < 0.35
+    pt, cam = np.nonzero(vis)
+    pt_ptr = np.zeros(201, np.int64)
+    np.cumsum(vis.sum(axis=1), out=pt_ptr[1:])
+    xy = _mvba.project(X, K2, R, t, pt_ptr, cam)
+    ref = np.stack(calc_projected_points(X, K2, R, t), axis=1)[pt, cam]
+    np.testing.assert_allclose(xy, ref, rtol=0, atol=1e-13)
+    with pytest.raises(ValueError):
+        _mvba.project(X, K, R, t, pt_ptr, np.full_like(cam, 10))
+    # the synthetic-scene generator on the device == on the host
+    a = make_scene(70_000, 12, vis_p=0.2, project="gpu")
+    b = make_scene(70_000, 12, vis_p=0.2, project="numpy")
+    np.testing.assert_array_equal(a.cam_idx, b.cam_idx)
+    np.testing.assert_allclose(a.xy, b.xy, rtol=0, atol=1e-13)

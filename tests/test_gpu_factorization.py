@@ -128,6 +128,80 @@ def test_config5_full_size_5m_rows_fp32():
     print(line)
 
 
+def _graded(n_rows, n_cols, sigmas, seed=0, noise=0.0):
+    rng = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(rng.normal(size=(n_rows, len(sigmas))))
+    V, _ = np.linalg.qr(rng.normal(size=(n_cols, len(sigmas))))
+    W = (U * np.asarray(sigmas)) @ V.T
+    if noise:
+        W = W + noise * rng.normal(size=W.shape)
+    return W
+
+
+def test_fp64_graded_spectrum_small_singular_values_like_gesdd():
+    """fp64 data with sigma_4 / sigma_1 = 1e-7 (the default n_rank = 4 path of
+    perspective_self_calibration USES the 4th triplet, ref :533): one Gram pass would leave sigma_4
+    good to ~1e-2 only; the preconditioned second pass must give it to ~eps * sigma_1 like LAPACK."""
+    sig = [1.0, 0.3, 1e-3, 1e-7]
+    Wt = _graded(200_000, 12, sig, noise=1e-13)
+    M, s, S, _mu, tm = _mvba.svd_factorize(Wt, 4)
+    U_ref, s_ref, Vt_ref = np.linalg.svd(Wt, full_matrices=False)
+    np.testing.assert_allclose(s[:4], s_ref[:4], rtol=1e-7)
+    assert abs(s[3] / s_ref[3] - 1.0) < 1e-7 and tm["refine_ms"] > 0
+    # 4th left singular vector of W (= right singular vector of Wt) up to sign
+    v4 = Vt_ref[3]
+    assert min(np.abs(M[:, 3] - v4).max(), np.abs(M[:, 3] + v4).max()) < 1e-6
+    np.testing.assert_allclose(M.T @ M, np.eye(4), atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(S, axis=1), s_ref[:4], rtol=1e-7)
+    np.testing.assert_allclose(S, M.T @ Wt.T, rtol=0, atol=1e-13)
+
+
+def test_fp64_centring_with_a_large_mean():
+    """|mean| = 1e6 x spread: G - s s^T / N would cancel 12 digits; the rows are centred before
+    they enter the Gram product (affine callers, ref affine_camera_calibration.py:224-240)."""
+    rng = np.random.default_rng(3)
+    Wt = _graded(100_000, 8, [50.0, 20.0, 5.0], seed=4, noise=1e-3) + 1e6 * (1.0 + rng.uniform(size=8))
+    M, s, S, mu, _ = _mvba.svd_factorize(Wt, 3, center=True)
+    Wc = Wt - Wt.mean(axis=0)
+    s_ref = np.linalg.svd(Wc, compute_uv=False)
+    np.testing.assert_allclose(mu, Wt.mean(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(s[:3], s_ref[:3], rtol=1e-9)
+    # S = M^T (W - mean) with the means the call returned (a 2e-14 relative difference between two
+    # fp64 means of 1e6-sized numbers is 3e-8 absolute: bigger than the tolerance on S itself)
+    np.testing.assert_allclose(S, M.T @ (Wt - mu).T, rtol=0, atol=1e-9 * np.abs(S).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_any_rank_and_workspace_reuse(dtype):
+    """n_rank beyond 4 (the reference takes any rank, ref factorization.py:6,12-13) and the resident
+    workspace: one load, several runs, identical to the one-shot call."""
+    Wt = _graded(50_000, 30, [9, 8, 7, 6, 5, 4, 3], seed=7, noise=1e-4).astype(dtype)
+    M, s, S, _mu, _ = _mvba.svd_factorize(Wt, 7)
+    s_ref = np.linalg.svd(Wt.astype(np.float64), compute_uv=False)
+    tol = 1e-5 if dtype == np.float32 else 1e-10
+    np.testing.assert_allclose(s[:7].astype(np.float64), s_ref[:7], rtol=tol)
+    M64, S64 = M.astype(np.float64), S.astype(np.float64)
+    np.testing.assert_allclose(M64.T @ M64, np.eye(7), atol=10 * tol)
+    np.testing.assert_allclose(S64, M64.T @ Wt.astype(np.float64).T, rtol=0, atol=10 * tol * np.abs(S64).max())
+    Mf, sf, Sf, _, _ = _mvba.svd_factorize(Wt, 30)  # full rank: every column of the basis
+    np.testing.assert_allclose(Mf.astype(np.float64).T @ Mf.astype(np.float64), np.eye(30), atol=10 * tol)
+    ws = _mvba.SvdWorkspace(60_000, 30, dtype)
+    ws.load(Wt)
+    M2, s2, S2, _, _ = ws.run(7)
+    Mc, sc_, Sc, muc, _ = ws.run(3, center=True)  # same resident matrix, no second upload
+    # same numbers as the one-shot call up to the Gram partial sums' atomic order (a few ulp)
+    np.testing.assert_allclose(M2, M, rtol=0, atol=(1e-6 if dtype == np.float32 else 1e-12))
+    np.testing.assert_allclose(S2, S, rtol=0, atol=(1e-5 if dtype == np.float32 else 1e-11) * np.abs(S64).max())
+    np.testing.assert_allclose(muc.astype(np.float64), Wt.astype(np.float64).mean(axis=0), atol=10 * tol)
+    ws.load(Wt[:1000])  # a smaller matrix in the same workspace
+    M3, s3, S3, _, _ = ws.run(3)
+    assert S3.shape == (3, 1000)
+    np.testing.assert_allclose(s3[:3].astype(np.float64), np.linalg.svd(Wt[:1000].astype(np.float64), compute_uv=False)[:3], rtol=tol)
+    with pytest.raises(ValueError):
+        ws.load(np.zeros((70_000, 30), dtype))
+    ws.close()
+
+
 def test_bad_arguments():
     with pytest.raises(ValueError):
         _mvba.svd_factorize(np.zeros((10, 4)), 5)
