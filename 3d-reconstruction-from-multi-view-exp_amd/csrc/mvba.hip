@@ -1646,6 +1646,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (p->n_points < 0 || p->n_images < 2 || p->n_obs < 0 || !p->pt_ptr || (p->n_obs && (!p->cam_idx || !p->xy)))
     return fail(MVBA_ERR_BADARG, "bad problem sizes or null arrays (need n_images >= 2)");
   if (p->gauge_axis != 0 && p->gauge_axis != 1) return fail(MVBA_ERR_BADARG, "gauge_axis must be 0 or 1");
+  // the kernels keep the whole camera table in LDS (K1: 19 doubles per camera + 8 x 8 KiB of wave
+  // tiles; back-substitution: 28 per camera): 160 KiB per workgroup caps the camera count
+  constexpr int MAX_CAMERAS = (160 * 1024 / 8 - 8 * 64 * 2 * 8 - 2) / 19;  // = 646
+  if (p->n_images > MAX_CAMERAS)
+    return fail(MVBA_ERR_BADARG, "n_images = " + std::to_string(p->n_images) + " exceeds the " + std::to_string(MAX_CAMERAS) +
+                                     " cameras whose parameter table fits the 160 KiB of LDS of one workgroup");
   if (p->pt_ptr[0] != 0 || p->pt_ptr[p->n_points] != p->n_obs) return fail(MVBA_ERR_BADARG, "pt_ptr does not span n_obs");
   if (p->n_obs >= (1LL << 31) || p->n_points >= (1LL << 31))
     return fail(MVBA_ERR_BADARG, "n_obs and n_points per handle must be < 2^31");

@@ -209,6 +209,8 @@ def test_error_behaviour_on_gpu(golden):
         eng.try_step(1e-4)  # before linearize
     with pytest.raises(ValueError):
         _mvba.HipEngine(3, 2, [0, 2, 4, 6], [0, 1, 1, 0, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
+    with pytest.raises(ValueError, match="646 cameras"):  # LDS camera-table ceiling is a stated limit, not a HIP error
+        _mvba.HipEngine(3, 647, [0, 2, 4, 6], [0, 1, 0, 1, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
 
 
 def test_profiling_stats_are_populated():
