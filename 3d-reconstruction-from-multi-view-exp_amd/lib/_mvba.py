@@ -46,6 +46,7 @@ SIGNATURES = {
     "mvba_destroy": (None, [C.c_void_p]),
     "mvba_set_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "mvba_get_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "mvba_apply_similarity": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double]),
     "mvba_cost": (C.c_int, [C.c_void_p, _dp]),
     "mvba_linearize": (C.c_int, [C.c_void_p]),
     "mvba_try_step": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -156,6 +157,12 @@ class HipEngine:
         t = np.empty((self.m, 3)); R = np.empty((self.m, 3, 3))
         raise_for(self.lib.mvba_get_params(self._h, _ptr(X), _ptr(f), _ptr(u), _ptr(t), _ptr(R)), self.lib)
         return X, f, u, t, R
+
+    def apply_similarity(self, R0, t0, scale):
+        """Committed state -> scale * X R0^T + t0 (likewise t), R0 R, on the device (ref :242-258)."""
+        R0, t0 = _as(R0, np.float64), _as(t0, np.float64)
+        assert R0.shape == (3, 3) and t0.shape == (3,)
+        raise_for(self.lib.mvba_apply_similarity(self._h, _ptr(R0), _ptr(t0), float(scale)), self.lib)
 
     def cost(self):
         E = C.c_double()

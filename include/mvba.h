@@ -86,6 +86,11 @@ int mvba_set_params(mvba_handle *h, const double *X, const double *f, const doub
                     const double *t, const double *R);
 int mvba_get_params(mvba_handle *h, double *X, double *f, double *u, double *t, double *R);
 
+/* The way back to the caller's frame, on the device and in place (ref :242-258, applied by the
+ * reference's optimize() before it returns, :198-200): X <- scale X R0^T + t0, t likewise,
+ * R <- R0 R on the committed state.  R0 [3][3] row-major, t0 [3]. */
+int mvba_apply_similarity(mvba_handle *h, const double *R0, const double *t0, double scale);
+
 /* E = sum over observations of |e|^2 at the committed state (ref :666-677). */
 int mvba_cost(mvba_handle *h, double *E);
 /* K1+K2 at the committed state (ref :103-116). */

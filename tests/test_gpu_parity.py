@@ -213,6 +213,29 @@ def test_error_behaviour_on_gpu(golden):
         _mvba.HipEngine(3, 647, [0, 2, 4, 6], [0, 1, 0, 1, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
 
 
+def test_device_way_back_to_the_input_frame_matches_the_host_formula():
+    """mvba_apply_similarity (k_similarity) == the reference's inverse transform (:242-258) that
+    optimize() used to apply with NumPy on the host."""
+    from lib.bundle_adjustment import from_gauge_frame
+
+    sc = make_scene(3000, 9, vis_p=0.6)
+    ba = BundleAdjuster.from_observations(sc.n_points, 9, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                          sc.init_R, sc.init_t, axis=sc.axis)
+    eng = ba._engine
+    X, f, u, t, R = eng.get_params()
+    cam0 = ba._init_camera0_params
+    Xg, Rg, tg = from_gauge_frame(cam0, X, R, t)
+    eng.apply_similarity(cam0["R"], cam0["t"], cam0["c0c1_len"])
+    X2, f2, u2, t2, R2 = eng.get_params()
+    np.testing.assert_allclose(X2, Xg, rtol=0, atol=1e-13 * np.abs(Xg).max())
+    np.testing.assert_allclose(t2, tg, rtol=0, atol=1e-13 * np.abs(tg).max())
+    np.testing.assert_allclose(R2, Rg, rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(f2, f)
+    np.testing.assert_array_equal(u2, u)
+    # the scene was generated in a frame where the way back is the identity up to rounding
+    np.testing.assert_allclose(X2, sc.init_X, rtol=0, atol=1e-12)
+
+
 def test_profiling_stats_are_populated():
     sc = make_scene(5000, 8, vis_p=0.5)
     ba = BundleAdjuster.from_observations(sc.n_points, 8, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
