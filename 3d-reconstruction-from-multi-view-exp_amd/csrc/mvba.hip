@@ -1550,6 +1550,9 @@ struct mvba_handle {
   int *d_flag = nullptr, *h_flag = nullptr;
   // comm
   ncclComm_t comm = nullptr;
+  mvba_host_allreduce_fn host_ar = nullptr;  // host-staged transport (mvba_comm_init_host) instead of RCCL
+  void *host_ar_user = nullptr;
+  std::vector<double> host_buf;
   int rank = 0, nranks = 1;
   double *d_allcost = nullptr, *h_allcost = nullptr, *d_sim = nullptr;
   // profiling
@@ -1627,7 +1630,17 @@ int global_cost(mvba_handle *h, double *E) {
   }
   int rc = sync_and_drain(h);
   if (rc) return rc;
-  if (h->comm) {
+  if (h->host_ar) {  // all-gather as a sum of one-hot slices: {cost, flags as a count} per rank
+    std::vector<double> v(2 * (size_t)h->nranks, 0.0);
+    v[2 * h->rank] = h->h_cost[0];
+    v[2 * h->rank + 1] = (double)*h->h_flag;  // small non-negative integer: exact in a double
+    if (h->host_ar(h->host_ar_user, v.data(), (int64_t)v.size())) return fail(MVBA_ERR_RCCL, "host all-reduce callback failed");
+    double s = 0.0;
+    int fl = 0;
+    for (int i = 0; i < h->nranks; ++i) { s += v[2 * i]; fl |= (int)v[2 * i + 1]; }
+    *E = s;
+    *h->h_flag = fl;
+  } else if (h->comm) {
     double s = 0.0;
     int fl = 0;
     for (int i = 0; i < h->nranks; ++i) {
@@ -2120,6 +2133,12 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_ALLREDUCE);
     ncclResult_t r = g_rccl.AllReduce(h->d_Ab, h->d_Ab, nA + n9, ncclDouble, ncclSum, h->comm, h->stream);
     if (r != ncclSuccess) return fail(MVBA_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  } else if (h->host_ar) {  // host-staged transport: D2H, caller's sum, H2D (no RCCL; see mvba_comm_init_host)
+    h->host_buf.resize(nA + n9);
+    MVBA_HIP(hipMemcpyAsync(h->host_buf.data(), h->d_Ab, sizeof(double) * (nA + n9), hipMemcpyDeviceToHost, h->stream));
+    MVBA_HIP(hipStreamSynchronize(h->stream));
+    if (h->host_ar(h->host_ar_user, h->host_buf.data(), (int64_t)(nA + n9))) return fail(MVBA_ERR_RCCL, "host all-reduce callback failed");
+    MVBA_HIP(hipMemcpyAsync(h->d_Ab, h->host_buf.data(), sizeof(double) * (nA + n9), hipMemcpyHostToDevice, h->stream));
   }
   {
     Timed t(h, MVBA_K_SOLVE);
@@ -2263,6 +2282,14 @@ int mvba_comm_init(mvba_handle *h, const void *id128, int32_t rank, int32_t n_ra
   int rc = dmalloc(&h->d_allcost, 2 * (size_t)n_ranks);
   if (rc) return rc;
   MVBA_HIP(hipHostMalloc((void **)&h->h_allcost, 2 * sizeof(double) * n_ranks));
+  return MVBA_OK;
+}
+
+int mvba_comm_init_host(mvba_handle *h, int32_t rank, int32_t n_ranks, mvba_host_allreduce_fn fn, void *user) {
+  if (!h || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MVBA_ERR_BADARG, "bad comm arguments");
+  if (h->comm) return fail(MVBA_ERR_STATE, "handle already has an RCCL communicator");
+  h->host_ar = fn; h->host_ar_user = user;
+  h->rank = rank; h->nranks = n_ranks;
   return MVBA_OK;
 }
 

@@ -62,6 +62,17 @@ def attach_rccl(engine, group=None):
     return rank, world
 
 
+def attach_host_comm(engine, group=None):
+    """Same job over the host-staged transport (``mvba_comm_init_host``): the packed reduced system
+    goes through a torch.distributed all-reduce on the host (gloo).  For hosts without RCCL and for
+    multi-process runs that share one GPU."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    engine.comm_init_host(rank, world, numpy_allreduce(group))
+    return rank, world
+
+
 def numpy_allreduce(group=None):
     """In-place float64 sum over ranks for host arrays (gloo); used to drive the
     CPU oracle engine through the same sharding logic in tests."""

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mvba_get_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mvba_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mvba_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mvba_comm_init_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mvba_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64, C.POINTER(C.c_int64)]),
     "mvba_host_obs_math": (C.c_int, [_dp, _dp, _dp, C.c_double, _dp]),
     "mvba_project": (C.c_int, [_dp, C.c_int64, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
@@ -212,6 +213,21 @@ class HipEngine:
     def comm_init(self, id128: bytes, rank: int, n_ranks: int):
         buf = C.create_string_buffer(bytes(id128), 128)
         raise_for(self.lib.mvba_comm_init(self._h, buf, int(rank), int(n_ranks)), self.lib)
+
+    def comm_init_host(self, rank: int, n_ranks: int, allreduce):
+        """Host-staged transport: ``allreduce(a)`` sums a float64 ndarray in place over the ranks."""
+        HOSTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int64)
+
+        def _cb(_user, buf, n):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        self._host_cb = HOSTFN(_cb)  # keep the trampoline alive as long as the engine
+        raise_for(self.lib.mvba_comm_init_host(self._h, int(rank), int(n_ranks), C.cast(self._host_cb, C.c_void_p), None),
+                  self.lib)
 
     def debug_read(self, name):
         n = C.c_int64()

@@ -120,6 +120,14 @@ int mvba_get_info(mvba_handle *h, int64_t *out8);
 int mvba_comm_unique_id(void *id128);
 int mvba_comm_init(mvba_handle *h, const void *id128, int32_t rank, int32_t n_ranks);
 
+/* The same sharded job over a HOST-STAGED transport instead of RCCL: the library copies the packed
+ * [A|b] (and the 16-byte cost/status record) to the host and calls `fn(user, buf, n)`, which must
+ * sum `buf` in place over all ranks (e.g. a gloo / MPI all-reduce) and return 0.  For machines
+ * without RCCL and for multi-process tests that share one GPU (RCCL refuses two ranks on one
+ * device); control flow, rank-ordered cost sum and collective error behaviour are identical. */
+typedef int (*mvba_host_allreduce_fn)(void *user, double *buf, int64_t n);
+int mvba_comm_init_host(mvba_handle *h, int32_t rank, int32_t n_ranks, mvba_host_allreduce_fn fn, void *user);
+
 /* Test hook: download an intermediate in canonical per-observation / per-point
  * row-major layout.  Returns the element count in *n (out may be NULL to query). */
 enum {
