@@ -9,7 +9,7 @@
 //   C1  ncclAllReduce    [A|b] across point shards                            
 //   K4  k_chol_super / k_chol_trail / k_chol_backsolve (+ k_lu_solve rescue)
 //                        dense solve of the gauge-reduced system              (ref :146)
-//   K5+K6 k_backsub_cost dX_a, trial state, trial cost                        (ref :152-162, :260-281, :666-677)
+//   K5+K6 k_backsub, k_cost  dX_a, trial state, trial cost                    (ref :152-162, :260-281, :666-677)
 // HBM layout: observations sorted by point (CSR).  The linearisation of ONE
 // observation is ONE 128-byte line ("record", 8 x double2 = (row0,row1) pairs):
 //   slot 0-2  J_X columns          slot 3    dJ/df
@@ -1332,57 +1332,50 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
       o[6 + 3 * r + cc] = Q[3 * r] * in[6 + cc] + Q[3 * r + 1] * in[9 + cc] + Q[3 * r + 2] * in[12 + cc];
 }
 
-// ------------------------------------------------------------------ K5+K6
-// Eight lanes per point, one observation per lane (a point's records are consecutive 128-byte
-// lines, so the 8 lanes of a group stream 1 KiB contiguous): every lane forms
-// y_o = 2 Jx^T (Jc dxi_k) for its observations, the group adds them up (3 values, 3 butterfly
-// steps per point), dX_a = -E^-1 (sum_o y_o + dP_a), X' = X + dX, then the point's residuals at
-// the trial cameras with the same lane <-> observation mapping.  Grid-stride over groups of 32
-// points; partials[block] = block cost (fixed tree, fixed grid -> deterministic).
-__global__ __launch_bounds__(256) void k_backsub_cost(
-    long long npts, int m, const long long *__restrict__ pt_ptr, const int *__restrict__ cam_idx,
-    const double2 *__restrict__ xy, const double2 *__restrict__ rec,
-    const double *__restrict__ PB, const double *__restrict__ dxi, const double *__restrict__ X,
-    const double *__restrict__ cam15_trial, double f0, double *__restrict__ Xt, double *__restrict__ dX,
-    double *__restrict__ partials) {
+// ------------------------------------------------------------------ K5
+// dX_a = -E_a^-1 (sum_o F_ao dxi_k + dP_a), X' = X + dX  (ref :152, :260-261).  Eight lanes per
+// point, one observation per lane.  The Jacobian rows of an observation are RECOMPUTED from the
+// committed point and the committed camera (LDS table) with the very function K1 used, instead of
+// re-reading the 128-byte records: the kernel then moves 24 B/point + 4 B/observation instead of
+// 128 B/observation (1.7 GB -> 0.25 GB at config 3) for ~150 fp64 operations per observation, which
+// the chip has to spare.  y_o = 2 Jx^T (Jc dxi_k) with the implied columns of the record form
+// ((u,v) -> 1/f0, t -> -J_X), so that it is the same linear map the Schur kernel assembled.
+// The trial cost is k_cost on the trial state (K6).
+__global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
+                                                 const int *__restrict__ cam_idx, const double *__restrict__ PB,
+                                                 const double *__restrict__ dxi, const double *__restrict__ X,
+                                                 const double *__restrict__ cam15, double f0, double *__restrict__ Xt,
+                                                 double *__restrict__ dX) {
   extern __shared__ double smem[];
   double *s_dxi = smem, *s_cam = smem + 9 * m;
-  __shared__ double s_red[16];
   for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
-  load_cams_to_lds(cam15_trial, m, f0, s_cam);
+  load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   const int s = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const double cu = 1.0 / f0;
-  double cost = 0.0;
   const long long a_first = (long long)blockIdx.x * 32 + grp, a_step = (long long)gridDim.x * 32;
   long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
   if (a_first < npts) { nx0 = pt_ptr[a_first]; nx1 = pt_ptr[a_first + 1]; }
   for (long long a = a_first; a < npts; a += a_step) {
     const long long o0 = nx0, o1 = nx1;
     if (a + a_step < npts) { nx0 = pt_ptr[a + a_step]; nx1 = pt_ptr[a + a_step + 1]; }
-    // everything this point needs is requested up front (point block, X, the lane's first
-    // observation for the cost pass): one memory latency per point instead of three
     const double *pb = PB + PBS * a;
     const double pb0 = pb[0], pb1 = pb[1], pb2 = pb[2], pb3 = pb[3], pb4 = pb[4], pb5 = pb[5], pb6 = pb[6], pb7 = pb[7],
                  pb8 = pb[8];
     const double Xa0 = X[3 * a], Xa1 = X[3 * a + 1], Xa2 = X[3 * a + 2];
-    const long long of = o0 + s;
-    const bool has_first = of < o1;
-    const double2 zf = has_first ? xy[of] : make_double2(0.0, 0.0);
-    const int cf = has_first ? cam_idx[of] : 0;
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    for (long long o = of; o < o1; o += 8) {
-      const double *dk = s_dxi + 9 * ((o == of) ? cf : cam_idx[o]);
-      const double2 *q = rec + o * REC;
-      const double2 x0 = q[0], x1 = q[1], x2 = q[2], jf = q[3], w0 = q[4], w1 = q[5], w2 = q[6];
-      // Jc dxi_k with the implied columns: (u,v) -> 1/f0, t -> -J_X
-      const double s0 = jf.x * dk[0] + cu * dk[1] - (x0.x * dk[3] + x1.x * dk[4] + x2.x * dk[5]) +
-                        (w0.x * dk[6] + w1.x * dk[7] + w2.x * dk[8]);
-      const double s1 = jf.y * dk[0] + cu * dk[2] - (x0.y * dk[3] + x1.y * dk[4] + x2.y * dk[5]) +
-                        (w0.y * dk[6] + w1.y * dk[7] + w2.y * dk[8]);
-      y0 += 2.0 * (x0.x * s0 + x0.y * s1);
-      y1 += 2.0 * (x1.x * s0 + x1.y * s1);
-      y2 += 2.0 * (x2.x * s0 + x2.y * s1);
+    for (long long o = o0 + s; o < o1; o += 8) {
+      const int k = cam_idx[o];
+      const double *dk = s_dxi + 9 * k;
+      ObsJ J;
+      obs_math(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, 0.0, 0.0, f0, J);
+      const double s0 = J.jc[0][0] * dk[0] + cu * dk[1] - (J.jx[0][0] * dk[3] + J.jx[0][1] * dk[4] + J.jx[0][2] * dk[5]) +
+                        (J.jc[0][6] * dk[6] + J.jc[0][7] * dk[7] + J.jc[0][8] * dk[8]);
+      const double s1 = J.jc[1][0] * dk[0] + cu * dk[2] - (J.jx[1][0] * dk[3] + J.jx[1][1] * dk[4] + J.jx[1][2] * dk[5]) +
+                        (J.jc[1][6] * dk[6] + J.jc[1][7] * dk[7] + J.jc[1][8] * dk[8]);
+      y0 += 2.0 * (J.jx[0][0] * s0 + J.jx[1][0] * s1);
+      y1 += 2.0 * (J.jx[0][1] * s0 + J.jx[1][1] * s1);
+      y2 += 2.0 * (J.jx[0][2] * s0 + J.jx[1][2] * s1);
     }
 #pragma unroll
     for (int msk = 1; msk < 8; msk <<= 1) {  // fixed butterfly: every lane ends with the group sum
@@ -1390,22 +1383,14 @@ __global__ __launch_bounds__(256) void k_backsub_cost(
       y1 += __shfl_xor(y1, msk, 8);
       y2 += __shfl_xor(y2, msk, 8);
     }
-    const double d0 = -(pb0 * y0 + pb1 * y1 + pb2 * y2) - pb6;
-    const double d1 = -(pb1 * y0 + pb3 * y1 + pb4 * y2) - pb7;
-    const double d2 = -(pb2 * y0 + pb4 * y1 + pb5 * y2) - pb8;
-    const double X0 = Xa0 + d0, X1 = Xa1 + d1, X2 = Xa2 + d2;
     if (s == 0) {
+      const double d0 = -(pb0 * y0 + pb1 * y1 + pb2 * y2) - pb6;
+      const double d1 = -(pb1 * y0 + pb3 * y1 + pb4 * y2) - pb7;
+      const double d2 = -(pb2 * y0 + pb4 * y1 + pb5 * y2) - pb8;
       dX[3 * a] = d0; dX[3 * a + 1] = d1; dX[3 * a + 2] = d2;
-      Xt[3 * a] = X0; Xt[3 * a + 1] = X1; Xt[3 * a + 2] = X2;
-    }
-    if (has_first) cost += obs_cost(X0, X1, X2, s_cam + cf * CAM_LDS, zf.x, zf.y, f0);
-    for (long long o = of + 8; o < o1; o += 8) {
-      const double2 z = xy[o];
-      cost += obs_cost(X0, X1, X2, s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
+      Xt[3 * a] = Xa0 + d0; Xt[3 * a + 1] = Xa1 + d1; Xt[3 * a + 2] = Xa2 + d2;
     }
   }
-  const double t = block_sum(cost, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
 // residual-only pass at a given state (initial cost, ref :85-87)
@@ -1982,7 +1967,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
-  TRYH(hipFuncSetAttribute((const void *)k_backsub_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
@@ -2170,11 +2155,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int nblk = (int)std::min<long long>(4096, (h->N + 31) / 32);
     if (nblk) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
-      hipLaunchKernelGGL(k_backsub_cost, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam,
-                         h->d_xy, h->d_rec, h->d_PB, h->d_dxi, h->d_X[h->cur], h->d_cam15[trial], h->f0,
-                         h->d_X[trial], h->d_dX, h->d_partials);
+      hipLaunchKernelGGL(k_backsub, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
+                         h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, nblk, h->d_cost, h->d_flag);
+    // K6: trial cost = the residual-only pass at the trial state (fixed grid, fixed tree: deterministic)
+    const size_t clds = (size_t)h->m * CAM_LDS * sizeof(double);
+    hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial], h->d_X[trial],
+                       h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag);
   };
   launch_tail();
   MVBA_HIP(hipGetLastError());
