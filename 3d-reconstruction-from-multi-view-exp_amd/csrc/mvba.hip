@@ -698,25 +698,41 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs(const int4 *__restrict__
 }
 
 // One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
+// One block per PAIR (blockIdx.x = packed pair index); the partials are loaded eight at a time (one
+// memory latency per eight units instead of one per unit: a diagonal pair has ~130 of them) and
+// added in unit order, so the result does not depend on the schedule.
 __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restrict__ unit_ptr,
                                                       const double *__restrict__ partial, double *__restrict__ Afull,
                                                       double *__restrict__ bfull, int *__restrict__ head) {
-  const int k = blockIdx.x, l = k + blockIdx.y;
-  if (l >= m) return;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) head[threadIdx.x] = 0;  // work queues for the next launch
-  const long long p = (long long)k * m - (long long)k * (k - 1) / 2 + (l - k);
+  if (blockIdx.x == 0 && threadIdx.x < 8) head[threadIdx.x] = 0;  // work queues for the next launch
+  // pair index -> (k, l): pairs of strip k start at k m - k (k - 1) / 2
+  const long long p = blockIdx.x;
+  int k = (int)((2.0 * m + 1.0 - sqrt((2.0 * m + 1.0) * (2.0 * m + 1.0) - 8.0 * (double)p)) * 0.5);
+  while ((long long)k * m - (long long)k * (k - 1) / 2 > p) --k;
+  while ((long long)(k + 1) * m - (long long)(k + 1) * k / 2 <= p) ++k;
+  const int l = k + (int)(p - ((long long)k * m - (long long)k * (k - 1) / 2));
   const int u0 = unit_ptr[p], u1 = unit_ptr[p + 1];
   const int e = threadIdx.x;
   if (e >= (k == l ? 99 : 81)) return;
-  double v = 0.0;
-  for (int uu = u0; uu < u1; ++uu) v += partial[(size_t)uu * UNIT_STRIDE + e];
+  auto ordered_sum = [&](int off) {
+    double v = 0.0;
+    int uu = u0;
+    for (; uu + 8 <= u1; uu += 8) {
+      double t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = partial[(size_t)(uu + q) * UNIT_STRIDE + off];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += t[q];
+    }
+    for (; uu < u1; ++uu) v += partial[(size_t)uu * UNIT_STRIDE + off];
+    return v;
+  };
+  const double v = ordered_sum(e);
   double *Ak = Afull + strip_offset(k, m);
   const int Wk = 9 * (m - k);
   if (e < 81) {
     const int i = e / 9, j = e - 9 * i;
-    double d = 0.0;
-    if (k == l && i == j)  // Marquardt damping of G_k's diagonal
-      for (int uu = u0; uu < u1; ++uu) d += partial[(size_t)uu * UNIT_STRIDE + 81 + i];
+    const double d = (k == l && i == j) ? ordered_sum(81 + i) : 0.0;  // Marquardt damping of G_k's diagonal
     Ak[(size_t)i * Wk + 9 * (l - k) + j] = v + d;
   } else if (e >= 90) {
     bfull[9 * k + (e - 90)] = v;
@@ -1900,7 +1916,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     h->n_units = (int)units.size();
   }
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
-  h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks, k_backsub_cost at most 4096
+  h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks
 
 #define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -2102,8 +2118,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     if (h->n_units)
       hipLaunchKernelGGL(k_schur_pairs, dim3((h->n_units + 3) / 4), dim3(256), 4 * 2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr,
                          h->d_q_units, h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
-    hipLaunchKernelGGL(k_schur_reduce, dim3(m, m), dim3(128), 0, h->stream, m, h->d_unit_ptr, h->d_partial, d_A, d_b,
-                       h->d_q_head);
+    hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,
+                       h->d_partial, d_A, d_b, h->d_q_head);
   } else if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
