@@ -614,15 +614,17 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const double v0 = t00 * sx[q] + t01 * sy[q], v1 = t10 * sx[q] + t11 * sy[q];
-        acc[0][q] += kf.x * v0 + kf.y * v1;
+        // two chained FMAs into the accumulator per row (written out: `acc += a*b + c*d` compiles to
+        // mul + fma + add, a third more fp64 instructions in a kernel whose VALU is 70 % busy)
+        acc[0][q] = fma(kf.y, v1, fma(kf.x, v0, acc[0][q]));
         acc[1][q] += v0;
         acc[2][q] += v1;
-        acc[3][q] += kx0.x * v0 + kx0.y * v1;
-        acc[4][q] += kx1.x * v0 + kx1.y * v1;
-        acc[5][q] += kx2.x * v0 + kx2.y * v1;
-        acc[6][q] += kw0.x * v0 + kw0.y * v1;
-        acc[7][q] += kw1.x * v0 + kw1.y * v1;
-        acc[8][q] += kw2.x * v0 + kw2.y * v1;
+        acc[3][q] = fma(kx0.y, v1, fma(kx0.x, v0, acc[3][q]));
+        acc[4][q] = fma(kx1.y, v1, fma(kx1.x, v0, acc[4][q]));
+        acc[5][q] = fma(kx2.y, v1, fma(kx2.x, v0, acc[5][q]));
+        acc[6][q] = fma(kw0.y, v1, fma(kw0.x, v0, acc[6][q]));
+        acc[7][q] = fma(kw1.y, v1, fma(kw1.x, v0, acc[7][q]));
+        acc[8][q] = fma(kw2.y, v1, fma(kw2.x, v0, acc[8][q]));
         if (DIAG) {
           dg[q] += sx[q] * sx[q] + sy[q] * sy[q];
           rb[q] += sx[q] * w0 + sy[q] * w1;
