@@ -1369,9 +1369,10 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
   for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
-  const int s = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  constexpr int G = 4;  // lanes per point
+  const int s = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   const double cu = 1.0 / f0;
-  const long long a_first = (long long)blockIdx.x * 32 + grp, a_step = (long long)gridDim.x * 32;
+  const long long a_first = (long long)blockIdx.x * (256 / G) + grp, a_step = (long long)gridDim.x * (256 / G);
   long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
   if (a_first < npts) { nx0 = pt_ptr[a_first]; nx1 = pt_ptr[a_first + 1]; }
   for (long long a = a_first; a < npts; a += a_step) {
@@ -1382,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
                  pb8 = pb[8];
     const double Xa0 = X[3 * a], Xa1 = X[3 * a + 1], Xa2 = X[3 * a + 2];
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    for (long long o = o0 + s; o < o1; o += 8) {
+    for (long long o = o0 + s; o < o1; o += G) {
       const int k = cam_idx[o];
       const double *dk = s_dxi + 9 * k;
       ObsJ J;
@@ -1396,10 +1397,10 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
       y2 += 2.0 * (J.jx[0][2] * s0 + J.jx[1][2] * s1);
     }
 #pragma unroll
-    for (int msk = 1; msk < 8; msk <<= 1) {  // fixed butterfly: every lane ends with the group sum
-      y0 += __shfl_xor(y0, msk, 8);
-      y1 += __shfl_xor(y1, msk, 8);
-      y2 += __shfl_xor(y2, msk, 8);
+    for (int msk = 1; msk < G; msk <<= 1) {  // fixed butterfly: every lane ends with the group sum
+      y0 += __shfl_xor(y0, msk, G);
+      y1 += __shfl_xor(y1, msk, G);
+      y2 += __shfl_xor(y2, msk, G);
     }
     if (s == 0) {
       const double d0 = -(pb0 * y0 + pb1 * y1 + pb2 * y2) - pb6;
@@ -2170,7 +2171,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_BACKSUB_COST);
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
-    const int nblk = (int)std::min<long long>(4096, (h->N + 31) / 32);
+    const int nblk = (int)std::min<long long>(4096, (h->N + 63) / 64);
     if (nblk) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
       hipLaunchKernelGGL(k_backsub, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
