@@ -316,7 +316,9 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
   // Workgroup barrier WITHOUT a compiler-level memory fence: a fencing __syncthreads() here
   // makes LLVM treat every later load as clobbered and turns the wave-uniform k-side loads
   // back into 64-lane vector loads (+70 VGPRs).  The LDS writes above are drained first.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // LDS-only: the zero-fill may not sink below the barrier
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
