@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--cams", type=int, default=None)
     ap.add_argument("--vis", type=float, default=None)
     ap.add_argument("--weak", action="store_true", help="N>1: a config-3-sized shard per GPU instead of config 4 split N ways")
+    ap.add_argument("--config4", action="store_true",
+                    help="N=1: run config 4 (10M points x 500 cameras x 5 %%, 250M observations) on the one GPU -- the N=1 point of "
+                         "the config-4 scaling curve; needs ~80 GB of HBM and a few minutes of index building")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +191,7 @@ def main():
     from lib.bundle_adjustment import BundleAdjuster, LevenbergMarquardt
     from lib.synthetic import make_scene, scene_shard
 
-    config4 = world > 1 and not args.weak
+    config4 = (world > 1 and not args.weak) or args.config4
     n_cams = args.cams or (500 if config4 else 100)
     vis = args.vis or (0.05 if config4 else 0.1)
     if config4:
