@@ -669,7 +669,8 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
   }
 }
 
-__global__ __launch_bounds__(256, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
+template <int WPB>  // waves per block (each wave works alone; a block only shares its launch and its LDS allocation)
+__global__ __launch_bounds__(64 * WPB, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
                                                         const int *__restrict__ q_units, int *__restrict__ head,
                                                         const int *__restrict__ it_k, const int *__restrict__ it_l,
                                                         const int *__restrict__ it_a, const double2 *__restrict__ rec,
@@ -678,22 +679,28 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs(const int4 *__restrict__
   extern __shared__ char smem_pairs[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   char *wbuf = smem_pairs + w * (2 * PWAVE_LDS);
-  // ---- pull one unit: own XCD's queue first, then the others (every queue entry is taken exactly
-  // once: the grid has as many waves as there are units, and a wave takes at most one)
-  int u = -1;
-  if (lane == 0) {
+  // ---- take one unit.  Dynamic (default): own XCD's queue first, then the others (every queue entry is
+  // taken exactly once: the grid has as many waves as there are units, and a wave takes at most
+  // one).  Static (head == nullptr; WPB = 1): block b takes entry b / 8 of queue b % 8 -- no atomic on
+  // the critical path, relies on the round-robin block -> XCD placement for locality only.
+  int pos = -1;
+  if (!head) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    if (q < q_ptr[x + 1] - q_ptr[x]) pos = q_ptr[x] + q;
+  } else if (lane == 0) {
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-    for (int t = 0; t < 8 && u < 0; ++t) {
+    for (int t = 0; t < 8 && pos < 0; ++t) {
       const int x = (xcc + t) & 7, len = q_ptr[x + 1] - q_ptr[x];
       if (len <= 0) continue;
       const int q = atomicAdd(&head[x], 1);
-      if (q < len) u = q_units[q_ptr[x] + q];
+      if (q < len) pos = q_ptr[x] + q;
     }
   }
-  u = __builtin_amdgcn_readfirstlane(u);
-  if (u < 0) return;
-  const int4 ud = units[u];
+  pos = __builtin_amdgcn_readfirstlane(pos);
+  if (pos < 0) return;
+  const int u = q_units[pos];   // unit id (where its partial goes) and descriptor, both in queue order:
+  const int4 ud = units[pos];   // two independent loads instead of a dependent pair
   const long long beg = ((long long)ud.y << 32) | (unsigned)ud.x;
   const int n = ud.z, cam_k = (int)((unsigned)ud.w >> 16), cam_l = ud.w & 0xffff;
   double *out = partial + (size_t)u * UNIT_STRIDE;
@@ -1536,7 +1543,7 @@ struct mvba_handle {
   // pair-major Schur index (k_schur_pairs): items sorted by (k, l, point), units, per-XCD work queues
   bool use_pairs = true;
   long long n_items = 0, n_items_offdiag = 0;
-  int n_units = 0, rccl_version = 0;
+  int n_units = 0, rccl_version = 0, q_max = 0;
   int *d_it_k = nullptr, *d_it_l = nullptr, *d_it_a = nullptr, *d_unit_ptr = nullptr, *d_q_ptr = nullptr, *d_q_units = nullptr,
       *d_q_head = nullptr;
   int4 *d_units = nullptr;
@@ -1973,7 +1980,14 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       TRYH(hipMemcpy(h->d_it_k, it_k.data(), sizeof(int) * it_k.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_l, it_l.data(), sizeof(int) * it_l.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_a, it_a.data(), sizeof(int) * it_a.size(), hipMemcpyHostToDevice));
-      TRYH(hipMemcpy(h->d_units, units.data(), sizeof(int4) * units.size(), hipMemcpyHostToDevice));
+      {
+        std::vector<int4> qdesc(units.size());  // descriptors in queue order (the kernel indexes both arrays by queue position)
+        for (size_t i = 0; i < q_units.size(); ++i) qdesc[i] = units[q_units[i]];
+        TRYH(hipMemcpy(h->d_units, qdesc.data(), sizeof(int4) * qdesc.size(), hipMemcpyHostToDevice));
+        int mx = 0;
+        for (int x = 0; x < 8; ++x) mx = std::max(mx, q_ptr[x + 1] - q_ptr[x]);
+        h->q_max = mx;
+      }
       TRYH(hipMemcpy(h->d_q_units, q_units.data(), sizeof(int) * q_units.size(), hipMemcpyHostToDevice));
     }
     TRYH(hipMemcpy(h->d_unit_ptr, unit_ptr.data(), sizeof(int) * P1, hipMemcpyHostToDevice));
@@ -2120,9 +2134,19 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   }
   if (h->use_pairs) {
     Timed t(h, MVBA_K_SCHUR);
-    if (h->n_units)
-      hipLaunchKernelGGL(k_schur_pairs, dim3((h->n_units + 3) / 4), dim3(256), 4 * 2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr,
-                         h->d_q_units, h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
+    if (h->n_units) {
+      static const int wpb = getenv("MVBA_PAIR_WPB") ? atoi(getenv("MVBA_PAIR_WPB")) : 1;  // experiment knobs
+      static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));
+      auto launch = [&](auto kern, int W) {
+        const bool st = stat && W == 1;
+        hipLaunchKernelGGL(kern, dim3(st ? 8 * h->q_max : (h->n_units + W - 1) / W), dim3(64 * W), W * 2 * PWAVE_LDS, h->stream,
+                           h->d_units, h->d_q_ptr, h->d_q_units, st ? nullptr : h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec,
+                           h->d_PB, c, h->f0, h->d_partial);
+      };
+      if (wpb == 1) launch(k_schur_pairs<1>, 1);
+      else if (wpb == 2) launch(k_schur_pairs<2>, 2);
+      else launch(k_schur_pairs<4>, 4);
+    }
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,
                        h->d_partial, d_A, d_b, h->d_q_head);
   } else if (h->nobs) {
