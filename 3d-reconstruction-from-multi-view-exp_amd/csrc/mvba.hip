@@ -768,8 +768,9 @@ constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 
 __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
-                          const double *__restrict__ bfull, double *__restrict__ M) {
+                          const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // i in [0, D], j in [0, D)
+  if (i == 0 && j == 0) *bar = 0u;  // k_chol_persist's barrier counter
   if (j >= D) return;
   const int gj = keep_index(j, gauge_axis);
   if (i == D) {
@@ -795,8 +796,12 @@ typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 // that A and B share is allowed.  Lane (idx = l & 15, kq = l >> 4) loads the 4 CONSECUTIVE
 // doubles X[idx][16 g + 4 kq .. + 3] (one 32-byte load; a row's 16-column group is one full
 // 128-byte line across kq) and feeds element u to MFMA step 4 g + u.
+// The load itself is UNCONDITIONAL (callers clamp p into the matrix): a load under a data-dependent
+// branch makes hipcc drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at the branch, which
+// turns a batch of independent loads into a chain of round trips.
 __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
-  return live ? *reinterpret_cast<const mvba_d4 *>(p) : mvba_d4{0.0, 0.0, 0.0, 0.0};
+  const mvba_d4 v = *reinterpret_cast<const mvba_d4 *>(p);
+  return live ? v : mvba_d4{0.0, 0.0, 0.0, 0.0};
 }
 
 // One launch per 128-column super-block [jS, jE).  Workgroup = 5 waves: wave 0 runs the serial
@@ -819,7 +824,7 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
 // MFMA layouts: A/B lane l holds X[idx = l & 15][k = 16 g + 4 (l >> 4) + u] at step (g, u)
 // (the k-permutation of load_k4); C/D: col = l & 15, row = (l >> 4) + 4 reg.
 constexpr int TS = NB + 1;                               // padded LDS tile row stride
-constexpr int SUPER_THREADS = 320;
+constexpr int SUPER_THREADS = 384;  // waves 0..5: chain, workers 0..2, an idle wave (keeps the chain alone on its SIMD), worker 3
 constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS + 64 * 9) * 8;  // 10 tiles + 2 Zt + Pt + panel buffer, bytes
 __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
@@ -908,54 +913,113 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
   return !bad;
 }
 
-__global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict__ M, int ld, int D, int jS,
-                                                              double *__restrict__ Ztiles, double *__restrict__ Lblk,
-                                                              int *__restrict__ flag) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void chol_super_body(double *lds, double *M, int ld, int D, int jS, double *__restrict__ Ztiles,
+                                                double *__restrict__ Lblk, int *__restrict__ flag, int bid, long long *trace = nullptr) {
+  int nst = 0;
+  auto st = [&](int who) { if (trace && bid == 0 && threadIdx.x == who) { trace[nst] = wall_clock64(); trace[64 + nst] = clock64(); } ++nst; };
+  st(0);
   double (*T)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);
   double (*Zt)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 10 * NB * TS);
   double (*Pt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 12 * NB * TS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ww = wave - 1;  // worker index (wave 0: -1)
+  const int ww = (wave == 0 || wave == 4) ? -1 : (wave == 5 ? 3 : wave - 1);  // worker index (chain and idle waves: -1)
   const int li = lane & 15, lk = lane >> 4;
   const int nbS = min(SBW, D - jS), jE = jS + nbS, nq = (nbS + NB - 1) / NB;
-  const int R0 = jE + blockIdx.x * 64 + 16 * ww;  // this worker's first row below the super-block
-  const bool wg0 = blockIdx.x == 0;
+  const int R0 = jE + bid * 64 + 16 * ww;  // this worker's first row below the super-block
+  const bool wg0 = bid == 0;
   const mvba_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  // workers: own rows of all four panels, C/D layout (issued first: consumed panel by panel)
+  // Loads, in the order they are needed (one CU draws ~25 GB/s from beyond its L2, so the 144 KiB a
+  // workgroup needs take ~8 us: the chain must not wait for all of it):
+  //   1. diagonal tile (0,0), by every thread -> LDS -> barrier: wave 0 starts factoring it
+  //   2. the workers' own rows of all four panels (C/D layout; consumed panel by panel) and the other
+  //      nine tiles of the diagonal block, by waves 1..5: in LDS before barrier B1 of panel 0
+  // (lower block triangle; identity padding beyond nbS).  The loads are UNCONDITIONAL on clamped
+  // addresses: behind a lane-dependent branch the compiler cannot count how many loads are in flight
+  // and waits for all of them (vmcnt(0)) at the first use.
+  // (the selection is done on the bit pattern: written as "cond ? loaded : other" the compiler sinks
+  // the load back under the branch)
+  auto pick = [](bool c, double loaded, double other) -> double {
+    const long long m = c ? -1LL : 0LL;
+    return __longlong_as_double((__double_as_longlong(loaded) & m) | (__double_as_longlong(other) & ~m));
+  };
+  // tile_raw requests an element, tile_fix (at the point of use, so that no wait is scheduled
+  // earlier) replaces what lies outside the lower triangle / the matrix by the identity padding
+  auto tile_raw = [&](int t, int idx) -> double {
+    const int r = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0, c = t - r * (r + 1) / 2;
+    const int i = idx >> 5, j = idx & 31, gi = NB * r + i, gj = NB * c + j, gic = min(gi, nbS - 1);
+    return M[(size_t)(jS + gic) * ld + jS + min(gj, gic)];
+  };
+  auto tile_fix = [&](int t, int idx, double raw) -> double {
+    const int r = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0, c = t - r * (r + 1) / 2;
+    const int i = idx >> 5, j = idx & 31, gi = NB * r + i, gj = NB * c + j;
+    return pick(idx < NB * NB && gi < nbS && gj <= gi, raw, (gi == gj) ? 1.0 : 0.0);
+  };
+  constexpr int P0 = (NB * NB + SUPER_THREADS - 1) / SUPER_THREADS;
+  constexpr int RT = SUPER_THREADS - 64, PR = (NB * NB + RT - 1) / RT;  // the rest: every wave but the chain
+  double v0[P0];
+#pragma unroll
+  for (int ps = 0; ps < P0; ++ps) v0[ps] = tile_raw(0, tid + ps * SUPER_THREADS);
+  if (trace && bid == 0 && threadIdx.x == 0) trace[47] = wall_clock64();
+  auto store_tile0 = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < P0; ++ps) {
+      const int idx = tid + ps * SUPER_THREADS;
+      if (idx < NB * NB) T[0][idx >> 5][idx & 31] = tile_fix(0, idx, v0[ps]);
+    }
+    if (trace && bid == 0 && threadIdx.x == 0) trace[48] = wall_clock64();
+    __syncthreads();  // tile (0,0) loaded
+  };
+  if (wave == 0) {
+    // ---- the chain: nothing else to load (its own code path, so that its wait counts only its loads)
+    store_tile0();
+    st(0);
+    for (int q = 0; q < nq; ++q) {
+      // ---- F
+      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lds + 12 * NB * TS + 64 * TS, lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
+      if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
+      st(0);
+      __syncthreads();  // B1: Zt[q & 1] ready; tiles (r,q), r > q, final
+      st(0);
+      __syncthreads();  // B2: X tiles of panel q complete
+      st(0);
+      __syncthreads();  // B3: tile (q+1,q+1) final
+      st(0);
+    }
+    st(0);
+    return;  // (of this inlined body: the caller's code after it still runs)
+  }
+  // ---- workers (and the idle wave): tile (0,0) first, so that the chain starts after ONE short round
+  // trip; their own loads follow in one batch and have the ~7 us of the first tile factorisation to land
+  store_tile0();
   double P[4][4][2];
+  double vr[9][PR];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {  // (the idle wave loads a clamped dummy row group like a worker)
+      const double *src = M + (size_t)min(max(R0 + lk + 4 * qq, 0), D) * ld + jS;
+      P[q][qq][0] = src[min(NB * q + li, nbS - 1)];
+      P[q][qq][1] = src[min(NB * q + 16 + li, nbS - 1)];
+    }
+#pragma unroll
+  for (int t = 1; t < 10; ++t)
+#pragma unroll
+    for (int ps = 0; ps < PR; ++ps) vr[t - 1][ps] = tile_raw(t, tid - 64 + ps * RT);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int row = R0 + lk + 4 * qq;
-      const double *src = M + (size_t)min(max(row, 0), D) * ld + jS + NB * q;
-      P[q][qq][0] = (ww >= 0 && row <= D && NB * q + li < nbS) ? src[li] : 0.0;
-      P[q][qq][1] = (ww >= 0 && row <= D && NB * q + 16 + li < nbS) ? src[16 + li] : 0.0;
-    }
-  // diagonal block -> LDS tiles (lower block triangle; identity padding beyond nbS); every load
-  // is issued before the first LDS store: one memory latency, not forty
-  {
-    constexpr int PASSES = (NB * NB + SUPER_THREADS - 1) / SUPER_THREADS;
-    double v[10][PASSES];
-#pragma unroll
-    for (int t = 0; t < 10; ++t) {
-      const int r = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0, c = t - r * (r + 1) / 2;
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int idx = tid + ps * SUPER_THREADS, i = idx >> 5, j = idx & 31, gi = NB * r + i, gj = NB * c + j;
-        v[t][ps] = (gi == gj) ? 1.0 : 0.0;
-        if (idx < NB * NB && gi < nbS && gj <= gi) v[t][ps] = M[(size_t)(jS + gi) * ld + jS + gj];
-      }
+      P[q][qq][0] = pick(ww >= 0 && row <= D && NB * q + li < nbS, P[q][qq][0], 0.0);
+      P[q][qq][1] = pick(ww >= 0 && row <= D && NB * q + 16 + li < nbS, P[q][qq][1], 0.0);
     }
 #pragma unroll
-    for (int t = 0; t < 10; ++t)
+  for (int t = 1; t < 10; ++t)
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int idx = tid + ps * SUPER_THREADS;
-        if (idx < NB * NB) T[t][idx >> 5][idx & 31] = v[t][ps];
-      }
-  }
+    for (int ps = 0; ps < PR; ++ps) {
+      const int idx = tid - 64 + ps * RT;
+      if (idx < NB * NB) T[t][idx >> 5][idx & 31] = tile_fix(t, idx, vr[t - 1][ps]);
+    }
   mvba_d4 XA[3][2];  // own rows' X of the earlier panels, A layout
 #pragma unroll
   for (int q = 0; q < 3; ++q) XA[q][0] = XA[q][1] = zero4;
@@ -1007,18 +1071,14 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
     for (int qq = 0; qq < 4; ++qq) T[tix(r, c)][16 * ih + lk + 4 * qq][16 * jh + li] -= acc[qq];
   };
 
-  __syncthreads();  // tiles loaded
-  // Role split by whole waves (both roles execute the same number of workgroup barriers per
-  // panel: F | B1 | T | B2 | U | B3).  Separate loops keep the chain's registers (a tile row)
+  // Role split by whole waves (every role executes the same number of workgroup barriers per
+  // panel: F | B1 | T | B2 | U | B3).  Separate code paths keep the chain's registers (a tile row)
   // and the workers' registers (own rows, A operands) out of each other's live ranges.
-  if (wave == 0) {
+  if (ww < 0) {  // the idle wave (the chain returned above)
     for (int q = 0; q < nq; ++q) {
-      // ---- F
-      const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lds + 12 * NB * TS + 64 * TS, lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
-      if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-      __syncthreads();  // B1: Zt[q & 1] ready; tiles (r,q), r > q, final
-      __syncthreads();  // B2: X tiles of panel q complete
-      __syncthreads();  // B3: tile (q+1,q+1) final
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
     }
     return;
   }
@@ -1101,14 +1161,20 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *__restrict
     mvba_d4 d0, d1;
     own_trsm(nq - 1, d0, d1);
   }
+  if (trace && bid == 0 && threadIdx.x == 64) trace[40] = wall_clock64();
+}
+
+__global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *M, int ld, int D, int jS, double *__restrict__ Ztiles,
+                                                              double *__restrict__ Lblk, int *__restrict__ flag) {
+  extern __shared__ double lds[];
+  chol_super_body(lds, M, ld, D, jS, Ztiles, Lblk, flag, blockIdx.x);
 }
 
 // Trailing update with f64 MFMA for the finished super-block [jS, jE): C -= P P^T on rows/cols
 // >= jE (jE - jS == SBW).  Block = 4 waves = 64x64 output tile, wave = 32x32.
-__global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int ld, int D, int jS, int jE) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = jE + blockIdx.y * 64 + (wave >> 1) * 32;
-  const int c0 = jE + blockIdx.x * 64 + (wave & 1) * 32;
+__device__ __forceinline__ void chol_trail_body(double *M, int ld, int D, int jS, int jE, int bx, int by, int wave, int lane) {
+  const int r0 = jE + by * 64 + (wave >> 1) * 32;
+  const int c0 = jE + bx * 64 + (wave & 1) * 32;
   if (c0 > r0 + 31 || r0 > D || c0 >= D) return;  // strictly upper tile or out of range
   mvba_d4 acc[2][2];
 #pragma unroll
@@ -1159,6 +1225,67 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
       }
 }
 
+// The same update for SMALL trailing matrices (fewer 64 x 64 tiles than CUs): one workgroup per 32 x 32
+// tile, the K = 128 columns split over its four waves (32 each) and the four partial tiles summed
+// through LDS.  A workgroup then loads 72 KiB instead of 160 KiB -- one CU draws only ~25 GB/s from
+// beyond its L2, which is what a 64 x 64 tile's 20 us were -- and four times as many CUs take part.
+__global__ __launch_bounds__(256) void k_chol_trail32(double *M, int ld, int D, int jS, int jE) {
+  __shared__ double part[4][NB][NB + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  // lower-triangle tile index -> (by, bx <= by)
+  const int t = blockIdx.x;
+  int by = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while (by * (by + 1) / 2 > t) --by;
+  while ((by + 1) * (by + 2) / 2 <= t) ++by;
+  const int bx = t - by * (by + 1) / 2;
+  const int r0 = jE + NB * by, c0 = jE + NB * bx;
+  // C (this thread's four elements), requested first
+  double cv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = threadIdx.x + 256 * q, rr = r0 + (e >> 5), cc = c0 + (e & 31);
+    cv[q] = M[(size_t)min(rr, D) * ld + min(cc, D - 1)];
+  }
+  mvba_d4 av[2][2], bv[2][2];  // [row group of 16][k group of 16]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      av[i][g] = *reinterpret_cast<const mvba_d4 *>(M + (size_t)min(r0 + 16 * i + li, D) * ld + jS + 32 * wave + 16 * g + 4 * lk);
+      bv[i][g] = *reinterpret_cast<const mvba_d4 *>(M + (size_t)min(c0 + 16 * i + li, D) * ld + jS + 32 * wave + 16 * g + 4 * lk);
+    }
+  mvba_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i][g][u], bv[j][g][u], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[wave][16 * i + lk + 4 * q][16 * j + li] = acc[i][j][q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = threadIdx.x + 256 * q, i = e >> 5, j = e & 31, rr = r0 + i, cc = c0 + j;
+    const double sum = (part[0][i][j] + part[1][i][j]) + (part[2][i][j] + part[3][i][j]);
+    if (rr <= D && cc < D && cc <= rr) M[(size_t)rr * ld + cc] = cv[q] - sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_trail(double *M, int ld, int D, int jS, int jE) {
+  chol_trail_body(M, ld, D, jS, jE, blockIdx.x, blockIdx.y, threadIdx.x >> 6, threadIdx.x & 63);
+}
+
 // L^T x = y (y = row D of M, overwritten by x), one launch per 128-column super-block, last one
 // first.  Launch for super-block [jS, jE), given the finished x of the super-block above it
 // [jE, jE2):
@@ -1169,21 +1296,22 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ M, int 
 //                     x_t = (L^-T tile) y_t is a 32x32 mat-vec (tiles from k_chol_super: no serial
 //                     substitution) and y -= L[tile rows][cols left of it in the super-block]^T x_t;
 //                     scatters x into the full 9m vector (zeros at the gauge slots).
-__global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, int ld, int D, int m, int gauge_axis,
-                                                        const double *__restrict__ Ztiles, const double *__restrict__ Lblk,
-                                                        double *__restrict__ dxi_full, int jS, int jE, int jE2) {
+__device__ __forceinline__ void chol_backsolve_body(double *M, int ld, int D, int m, int gauge_axis,
+                                                    const double *Ztiles, const double *Lblk, double *dxi_full, int jS, int jE,
+                                                    int jE2, int bid, int tid) {
   __shared__ double xp[SBW];  // x of the super-block above
   __shared__ double ys[SBW];  // y, then x, of this super-block
   __shared__ double part[2][SBW];
   __shared__ double T[NB][NB + 1];
+  const bool act = tid < 256;  // the body is written for 256 threads; further threads only keep the barriers company
   double *y = M + (size_t)D * ld;
-  const int tid = threadIdx.x;
   const int np = jE2 - jE;  // 0 for the first launch (top super-block)
+  __syncthreads();          // a previous call's readers of xp / ys are done
   if (tid < SBW) xp[tid] = (tid < np) ? y[jE + tid] : 0.0;
   __syncthreads();
-  if (blockIdx.x > 0) {
-    const int c = (blockIdx.x - 1) * 256 + tid;
-    if (c < jS) {
+  if (bid > 0) {
+    const int c = (bid - 1) * 256 + tid;
+    if (act && c < jS) {
       const double *col = M + (size_t)jE * ld + c;
       double s0 = 0.0, s1 = 0.0;
       int r = 0;
@@ -1206,25 +1334,26 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, 
   {
     const int c = tid & (SBW - 1), h = tid >> 7;  // two threads per column, alternate rows
     double s = 0.0;
-    if (c < ns) {
+    if (act && c < ns) {
       const double *col = M + (size_t)jE * ld + jS + c;
 #pragma unroll 8
       for (int r = h; r < np; r += 2) s += col[(size_t)r * ld] * xp[r];
     }
-    part[h][c] = s;
+    if (act) part[h][c] = s;
     __syncthreads();
     if (tid < SBW) ys[tid] = (tid < ns) ? y[jS + tid] - part[0][tid] - part[1][tid] : 0.0;
-    if (np == 0)  // first launch on the stream: clear the gauge slots before any x is scattered
-      for (int i = tid; i < 9 * m; i += blockDim.x) dxi_full[i] = 0.0;
+    if (np == 0 && act)  // first launch on the stream: clear the gauge slots before any x is scattered
+      for (int i = tid; i < 9 * m; i += 256) dxi_full[i] = 0.0;
     __syncthreads();
   }
   const int lane = tid & 63, wave = tid >> 6;
   for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
     const int jb = jS + t * NB, nb = min(NB, jE - jb);
-    for (int q = tid; q < NB * NB; q += blockDim.x) {
-      const int r = q / NB, c = q % NB;
-      T[r][c] = (r < nb && c >= r && c < nb) ? Ztiles[(size_t)(jb / NB) * NB * NB + q] : 0.0;
-    }
+    if (act)
+      for (int q = tid; q < NB * NB; q += 256) {
+        const int r = q / NB, c = q % NB;
+        T[r][c] = (r < nb && c >= r && c < nb) ? Ztiles[(size_t)(jb / NB) * NB * NB + q] : 0.0;
+      }
     // operands of this tile's update inside the super-block, one column per thread
     double lcol[NB];
 #pragma unroll
@@ -1255,6 +1384,251 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double *__restrict__ M, 
     y[jS + tid] = ys[tid];
     dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
   }
+}
+
+__global__ __launch_bounds__(256) void k_chol_backsolve(double *M, int ld, int D, int m, int gauge_axis,
+                                                        const double *__restrict__ Ztiles, const double *__restrict__ Lblk,
+                                                        double *__restrict__ dxi_full, int jS, int jE, int jE2) {
+  chol_backsolve_body(M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, jS, jE, jE2, blockIdx.x, threadIdx.x);
+}
+
+// ---- the whole factor-and-solve as ONE launch: the phases above run back to back inside a persistent
+// grid, separated by device-wide barriers instead of kernel boundaries (a boundary on this chip costs
+// ~10 us of drain + cache write-back + dispatch; 20 of them were most of the 0.5 ms solve at D = 893).
+// Every workgroup runs the same phase sequence and reaches every barrier (the counts depend on D only),
+// the grid is at most one workgroup per CU, and a barrier gives up after ~2^22 polls (flag bit 8 ->
+// MVBA_ERR_HIP on the host) instead of spinning for ever, so the grid always drains.
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int *flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's global writes are visible device-wide
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) {
+        atomicOr(flag, 8);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // and the other workgroups' writes are visible to this wave
+}
+
+// The phases are CALLED, not inlined: each keeps the register allocation it has as a kernel of its own
+// (inlined into one loop nest the compiler spills ~150 VGPRs).
+__device__ __noinline__ void chol_super_call(double *lds, double *M, int ld, int D, int jS, double *Ztiles, double *Lblk, int *flag,
+                                             int bid, long long *trace) {
+  chol_super_body(lds, M, ld, D, jS, Ztiles, Lblk, flag, bid, trace);
+}
+__device__ __noinline__ void chol_trail_call(double *M, int ld, int D, int jS, int jE, int bx, int by, int wave, int lane) {
+  chol_trail_body(M, ld, D, jS, jE, bx, by, wave, lane);
+}
+__device__ __noinline__ void chol_backsolve_call(double *M, int ld, int D, int m, int gauge_axis, const double *Ztiles,
+                                                 const double *Lblk, double *dxi_full, int jS, int jE, int jE2, int bid, int tid) {
+  chol_backsolve_body(M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, jS, jE, jE2, bid, tid);
+}
+
+__device__ __noinline__ unsigned chol_backsolve_persist(double *lds, double *M, int ld, int D, int m, int gauge_axis,
+                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full, unsigned *bar,
+                                                       unsigned epoch, int *flag, long long *trace);
+
+__global__ __launch_bounds__(SUPER_THREADS) void k_chol_persist(double *M, int ld, int D, int m, int gauge_axis, double *Ztiles,
+                                                                double *Lblk, double *dxi_full, int *flag, unsigned *bar,
+                                                                long long *trace) {
+  extern __shared__ double lds[];
+  const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned epoch = 0;
+  int nstamp = 0;
+  auto stamp = [&]() {  // MVBA_CHOL_TRACE: workgroup 0's 100 MHz clock at every phase boundary
+    if (trace && bid == 0 && tid == 0) trace[nstamp] = wall_clock64();
+    ++nstamp;
+  };
+  stamp();
+  for (int jS = 0; jS < D; jS += SBW) {
+    const int jE = min(jS + SBW, D), nsup = (D + 1 - jE + 63) / 64;
+    for (int b = bid; b < nsup; b += G) {
+      chol_super_call(lds, M, ld, D, jS, Ztiles + (size_t)(jS / NB) * NB * NB, Lblk + (size_t)(jS / SBW) * SBW * SBW, flag, b,
+                      (trace && jS == SBW) ? trace + 128 : nullptr);
+      __syncthreads();  // (only when one workgroup serves several row groups: LDS is reused)
+    }
+    stamp();
+    grid_barrier(bar, ++epoch * G, flag);
+    stamp();
+    if (jE < D) {
+      // lower triangle of the nsup x nsup grid of 64 x 64 tiles, one wave per 32 x 32 quadrant
+      const int ntile = nsup * (nsup + 1) / 2;
+      if (wave < 4)
+        for (int t = bid; t < ntile; t += G) {
+          int by = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+          while (by * (by + 1) / 2 > t) --by;
+          while ((by + 1) * (by + 2) / 2 <= t) ++by;
+          chol_trail_call(M, ld, D, jS, jE, t - by * (by + 1) / 2, by, wave, lane);
+        }
+      stamp();
+      grid_barrier(bar, ++epoch * G, flag);
+      stamp();
+    }
+  }
+  chol_backsolve_persist(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, bar, epoch, flag, trace ? trace + 256 : nullptr);
+}
+
+// ---- L^T x = y for all super-blocks in one persistent pass (last block first).  Per step s:
+//   workgroup 0 ("chain")  y_s -= (rows of the block above)^T x_{s+1}; then the block's four tiles from the
+//                          bottom: x_t = Z_t y_t (Z = L_tt^-T from the factorisation), y_{t' < t} -= L[t][t']^T x_t.
+//                          Everything static it needs (Z tiles, the in-block L tiles, the 128 x 128 panel of the
+//                          block above) is requested in ONE batch at the start of the step together with y_s, the
+//                          tile chain then runs out of LDS and registers.
+//   workgroups >= 1        y[c] -= (rows of block s+1)^T x_{s+1} for the columns left of block s, 32 columns x
+//                          8 row chunks per workgroup: one batch of 16 loads per thread, LDS reduction.
+// One device-wide barrier per step (x_s must reach the other workgroups, their updates the chain).
+__device__ __forceinline__ unsigned chol_backsolve_persist_body(double *lds, double *M, int ld, int D, int m, int gauge_axis,
+                                                                const double *Ztiles, const double *Lblk_all, double *dxi_full,
+                                                                unsigned *bar, unsigned epoch, int *flag, long long *trace) {
+  const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool act = tid < 256;
+  double *y = M + (size_t)D * ld;
+  const int S = (D + SBW - 1) / SBW;
+  double (*Zs)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);                // [4]
+  double (*Ls)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 4 * NB * TS);  // [6]: in-block tile (r, c < r) at r (r - 1) / 2 + c
+  double *ys = lds + 10 * NB * TS, *xp = ys + SBW, *part = xp + SBW;               // part[3][SBW]; bulk: red[8][32]
+  int nst = 0;
+  auto st = [&]() { if (trace && bid == 0 && tid == 0) trace[nst] = wall_clock64(); ++nst; };
+  if (bid == 0) {
+    if (act)
+      for (int i = tid; i < 9 * m; i += 256) dxi_full[i] = 0.0;  // the gauge slots stay zero
+    if (tid < SBW) xp[tid] = 0.0;
+  }
+  for (int s = S - 1; s >= 0; --s) {
+    const int jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), ns = jE - jS, np = jE2 - jE;
+    st();
+    if (bid == 0) {
+      // ---- one batch of loads (all SUPER_THREADS threads).  Every load is "uniform base + one per-thread
+      // offset", so the addresses live in SGPRs and the batch fits the register file without spills.
+      const double *Lblk = Lblk_all + (size_t)s * SBW * SBW;
+      constexpr int NT = SUPER_THREADS, NPASS = (NB * NB + NT - 1) / NT, NPN = (SBW + 2) / 3;
+      double zl[10][NPASS], pn[NPN];
+#pragma unroll
+      for (int tile = 0; tile < 10; ++tile) {
+        // tiles 0..3: Z (upper triangle of L_tt^-T); 4..9: in-block L tile (tr, tc < tr)
+        const int e = tile - 4, tr = (e >= 3) ? 3 : (e >= 1) ? 2 : 1, tc = e - tr * (tr - 1) / 2;
+        const double *base = (tile < 4) ? Ztiles + (size_t)(jS / NB + tile) * NB * NB : Lblk + (size_t)(NB * tr) * SBW + NB * tc;
+        const int nb = ns - NB * (tile < 4 ? tile : tr);  // valid rows (and columns, for Z) of the tile
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int w = tid + NT * ps, r = w >> 5, c = w & 31;
+          const bool ok = w < NB * NB && r < nb && (tile >= 4 || (c >= r && c < nb));
+          zl[tile][ps] = ok ? base[tile < 4 ? w : r * SBW + c] : 0.0;
+        }
+      }
+      const int pc = tid & (SBW - 1), ph = tid >> 7;  // three threads per column, every third row
+      const int poff = ph * ld + pc;
+#pragma unroll
+      for (int i = 0; i < NPN; ++i) {
+        const double *rowbase = M + (size_t)(jE + 3 * i) * ld + jS;  // uniform
+        pn[i] = (pc < ns && ph + 3 * i < np) ? rowbase[poff] : 0.0;
+      }
+      const double yv = (tid < ns) ? y[jS + tid] : 0.0;
+      // ---- to LDS; the block above's share of y_s
+#pragma unroll
+      for (int tile = 0; tile < 10; ++tile)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int w = tid + NT * ps;
+          if (w < NB * NB) Zs[tile][w >> 5][w & 31] = zl[tile][ps];  // Ls follows Zs: tile 4 + e lands in Ls[e]
+        }
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int i = 0; i + 1 < NPN; i += 2) {
+        sa += pn[i] * xp[ph + 3 * i];
+        sb += pn[i + 1] * xp[ph + 3 * i + 3];
+      }
+      if (NPN & 1) sa += pn[NPN - 1] * xp[min(ph + 3 * (NPN - 1), SBW - 1)];  // (pn = 0 when that row does not exist)
+      part[ph * SBW + pc] = sa + sb;
+      __syncthreads();
+      if (tid < SBW) ys[tid] = (tid < ns) ? yv - part[tid] - part[SBW + tid] - part[2 * SBW + tid] : 0.0;
+      __syncthreads();
+      st();
+      // ---- the tile chain
+      for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
+        if (wave == 0) {
+          const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < NB / 2; q += 2) {
+            s0 += Zs[t][r][16 * h + q] * ys[t * NB + 16 * h + q];
+            s1 += Zs[t][r][16 * h + q + 1] * ys[t * NB + 16 * h + q + 1];
+          }
+          double xr = s0 + s1;
+          xr += __shfl_xor(xr, 32, 64);
+          if (lane < NB) ys[t * NB + lane] = xr;  // rows beyond the block's end: Zs row = 0 -> 0
+        }
+        __syncthreads();
+        if (tid < t * NB) {
+          const double (*Lt)[TS] = Ls[t * (t - 1) / 2 + (tid >> 5)];
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) sacc += Lt[r][tid & 31] * ys[t * NB + r];
+          ys[tid] -= sacc;
+        }
+        __syncthreads();
+      }
+      if (tid < SBW) xp[tid] = ys[tid];  // x_s: the next step's "block above"
+      if (tid < ns) {
+        y[jS + tid] = ys[tid];
+        dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
+      }
+      st();
+    } else if (np > 0) {
+      // ---- bulk: columns left of block s, rows of block s+1
+      double *red = part;
+      const int cj = tid & 31, ch = tid >> 5, ngrp = (jS + 31) / 32;
+      for (int g = bid - 1; g < ngrp; g += G - 1) {
+        const int c = 32 * g + cj;
+        double lv[16], xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = 16 * ch + u;
+          const bool ok = act && c < jS && r < np;
+          lv[u] = ok ? M[(size_t)(jE + r) * ld + c] : 0.0;
+          xv[u] = ok ? y[jE + r] : 0.0;
+        }
+        const double yc = (tid < 32 && c < jS) ? y[c] : 0.0;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          s0 += lv[u] * xv[u];
+          s1 += lv[u + 1] * xv[u + 1];
+        }
+        if (act) red[ch * 32 + cj] = s0 + s1;
+        __syncthreads();
+        if (tid < 32 && c < jS) {
+          double tot = 0.0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) tot += red[k * 32 + cj];
+          y[c] = yc - tot;
+        }
+        __syncthreads();
+      }
+    }
+    if (s > 0) grid_barrier(bar, ++epoch * G, flag);
+  }
+  st();
+  return epoch;
+}
+
+__global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M, int ld, int D, int m, int gauge_axis,
+                                                                      const double *Ztiles, const double *Lblk, double *dxi_full,
+                                                                      int *flag, unsigned *bar, long long *trace) {
+  extern __shared__ double lds[];
+  chol_backsolve_persist_body(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, bar, 0u, flag, trace);
+}
+
+__device__ __noinline__ unsigned chol_backsolve_persist(double *lds, double *M, int ld, int D, int m, int gauge_axis,
+                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full, unsigned *bar,
+                                                       unsigned epoch, int *flag, long long *trace) {
+  return chol_backsolve_persist_body(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk_all, dxi_full, bar, epoch, flag, trace);
 }
 
 // ---- fallback: LU with partial pivoting (what np.linalg.solve / LAPACK gesv does, ref :146) ----
@@ -1561,6 +1935,9 @@ struct mvba_handle {
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
   int *d_flag = nullptr, *h_flag = nullptr;
+  unsigned *d_bar = nullptr;
+  long long *d_trace = nullptr;
+  int chol_mode = 1, chol_grid = 1, chol_grid_max = 1;  // 0: one launch per phase, 1: persistent grid, 2: persistent grid, cooperative launch
   // comm
   ncclComm_t comm = nullptr;
   mvba_host_allreduce_fn host_ar = nullptr;  // host-staged transport (mvba_comm_init_host) instead of RCCL
@@ -1956,6 +2333,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_partials, h->n_partials));
   TRY(dmalloc(&h->d_cost, 2));
   TRY(dmalloc(&h->d_flag, 1));
+  TRY(dmalloc(&h->d_bar, 1));
   TRYH(hipHostMalloc((void **)&h->h_cost, 2 * sizeof(double)));
   h->h_flag = reinterpret_cast<int *>(h->h_cost + 1);  // cost and flags come back in one copy
   TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
@@ -2004,6 +2382,21 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
+  {
+    // persistent solve: one workgroup per CU at most (its LDS fills a CU), enough of them for the widest phase
+    int ncu = 0, per_cu = 0;
+    TRYH(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+    TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_persist, SUPER_THREADS, SUPER_LDS));
+    const int nsup0 = (h->D + 1 - std::min(SBW, h->D) + 63) / 64;
+    h->chol_grid_max = ncu;
+    h->chol_grid = std::max(h->D > SBW ? 2 : 1, std::min(ncu, std::max(nsup0, nsup0 * (nsup0 + 1) / 2)));
+    h->chol_mode = per_cu >= 1 ? 3 : 0;
+    if (const char *ev = getenv("MVBA_CHOL"))
+      h->chol_mode = !strcmp(ev, "launches") ? 0 : !strcmp(ev, "persist") ? 1 : !strcmp(ev, "coop") ? 2 : !strcmp(ev, "hybrid") ? 3 : h->chol_mode;
+    if (const char *ev = getenv("MVBA_CHOL_GRID")) h->chol_grid = std::max(1, std::min(ncu, atoi(ev)));
+  }
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
@@ -2021,7 +2414,7 @@ void mvba_destroy(mvba_handle *h) {
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
-                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim};
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_trace};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_allcost) hipHostFree(h->h_allcost);
@@ -2174,21 +2567,62 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_SOLVE);
     const int ld = h->ld;
     hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
-                       h->d_Ared);
+                       h->d_Ared, h->d_bar);
+    if (h->chol_mode == 1 || h->chol_mode == 2) {  // one persistent launch (see k_chol_persist)
+      static const bool trace_on = getenv("MVBA_CHOL_TRACE") != nullptr;
+      if (trace_on && !h->d_trace) MVBA_HIP(hipMalloc(&h->d_trace, 1024 * sizeof(long long)));
+      void *args[] = {&h->d_Ared, (void *)&ld, (void *)&D, (void *)&m, &h->gauge_axis, &h->d_Ztiles, &h->d_Lblk, &h->d_dxi, &h->d_flag, &h->d_bar, &h->d_trace};
+      if (h->chol_mode == 2)
+        MVBA_HIP(hipLaunchCooperativeKernel((const void *)k_chol_persist, dim3(h->chol_grid), dim3(SUPER_THREADS), args, SUPER_LDS, h->stream));
+      else
+        hipLaunchKernelGGL(k_chol_persist, dim3(h->chol_grid), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, m,
+                           h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->d_trace);
+      if (trace_on) {  // debugging aid: phase times of workgroup 0, in microseconds
+        std::vector<long long> ts(1024);
+        MVBA_HIP(hipStreamSynchronize(h->stream));
+        MVBA_HIP(hipMemcpy(ts.data(), h->d_trace, sizeof(long long) * 1024, hipMemcpyDeviceToHost));
+        const int S = (D + SBW - 1) / SBW, n = 1 + 2 * S + 2 * (S - 1) + 2 * S;
+        fprintf(stderr, "chol trace (us):");
+        for (int i = 1; i < n; ++i) fprintf(stderr, " %.1f", (ts[i] - ts[i - 1]) * 0.01);
+        fprintf(stderr, "  total %.1f\n", (ts[n - 1] - ts[0]) * 0.01);
+        fprintf(stderr, "super-block 1 chain wave (us from entry):");
+        for (int i = 1; i < 19; ++i) fprintf(stderr, " %.1f", (ts[128 + i] - ts[128]) * 0.01);
+        fprintf(stderr, "  workers done %.1f; tile(0,0): requested %.2f, stored %.2f\n", (ts[128 + 40] - ts[128]) * 0.01,
+                (ts[128 + 47] - ts[128]) * 0.01, (ts[128 + 48] - ts[128]) * 0.01);
+        fprintf(stderr, "back-substitution steps (us: loads+panel, chain, publish+barrier):");
+        for (int i2 = 0; i2 < (D + SBW - 1) / SBW; ++i2)
+          fprintf(stderr, " [%.1f %.1f %.1f]", (ts[256 + 3 * i2 + 1] - ts[256 + 3 * i2]) * 0.01, (ts[256 + 3 * i2 + 2] - ts[256 + 3 * i2 + 1]) * 0.01,
+                  (ts[256 + 3 * i2 + 3] - ts[256 + 3 * i2 + 2]) * 0.01);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "same in clock64 ticks:");
+        for (int i = 1; i < 19; ++i) fprintf(stderr, " %lld", ts[128 + 64 + i] - ts[128 + 64]);
+        fprintf(stderr, "\n");
+      }
+    } else {
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
       hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
                          h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
-        const int nt = (D + 1 - jE + 63) / 64;
-        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
+        const int nt = (D + 1 - jE + 63) / 64, nt32 = (D + 1 - jE + NB - 1) / NB;
+        static const int small_max = getenv("MVBA_TRAIL32_MAX") ? atoi(getenv("MVBA_TRAIL32_MAX")) : 2 * h->chol_grid_max;
+        if (nt * (nt + 1) / 2 <= small_max)
+          hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
+        else
+          hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
+    if (h->chol_mode == 3) {  // launches for the factorisation, one persistent pass for L^T x = y
+      const int ngrp = (((D - 1) / SBW) * SBW + 31) / 32;
+      hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(h->chol_grid_max, 1 + ngrp)), dim3(SUPER_THREADS), SUPER_LDS, h->stream,
+                         h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->d_trace);
+    } else
     for (int jS = ((D - 1) / SBW) * SBW; jS >= 0; jS -= SBW) {
       const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
       const int nwg = (jE == D) ? 1 : 1 + (jS + 255) / 256;
       hipLaunchKernelGGL(k_chol_backsolve, dim3(nwg), dim3(256), 0, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles,
                          h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_dxi, jS, jE, jE2);
+    }
     }
   }
   MVBA_HIP(hipGetLastError());
@@ -2214,7 +2648,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   h->stats.n_try_step++;
   int rc = global_cost(h, E_trial);
   if (rc) return rc;
-  if ((*h->h_flag & 2) && !(*h->h_flag & 1)) {
+  if ((*h->h_flag & 2) && !(*h->h_flag & (1 | 8))) {
     // The Cholesky met a non-positive pivot: the reduced system is not positive definite (e.g. a
     // negative damping factor).  The reference's np.linalg.solve is LU with partial pivoting and
     // does not care, so redo the solve that way (slow path, rare) and the tail of the step.
@@ -2239,6 +2673,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (*h->h_flag) {
     const int fl = *h->h_flag;
     hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
+    if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_persist: a device-wide barrier timed out (is another process holding the CUs?)");
     return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system)");
   }
   h->have_trial = true;
