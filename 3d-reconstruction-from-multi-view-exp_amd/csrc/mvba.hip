@@ -770,7 +770,7 @@ constexpr int SBW = 4 * NB;
 __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
                           const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // i in [0, D], j in [0, D)
-  if (i == 0 && j == 0) *bar = 0u;  // k_chol_persist's barrier counter
+  if (i == 0 && j == 0) *bar = 0u;  // k_chol_backsolve_all's barrier counter
   if (j >= D) return;
   const int gj = keep_index(j, gauge_axis);
   if (i == D) {
@@ -826,6 +826,7 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
 constexpr int TS = NB + 1;                               // padded LDS tile row stride
 constexpr int SUPER_THREADS = 384;  // waves 0..5: chain, workers 0..2, an idle wave (keeps the chain alone on its SIMD), worker 3
 constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS + 64 * 9) * 8;  // 10 tiles + 2 Zt + Pt + panel buffer, bytes
+constexpr int BACKSOLVE_LDS = (10 * NB * TS + 4 * SBW) * 8;  // k_chol_backsolve_all: 10 tiles + y + partial sums, bytes
 __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
 // Tile factorisation on one wave (see F above); returns false if a pivot is not positive.
@@ -838,6 +839,9 @@ __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 //      B operands are both read from Xb (B operand of column tile ct = A operand of row tile ct)
 // 112 broadcast-FMAs + 32 MFMAs instead of 496 broadcast-FMAs: ~21k -> ~10k cycles per tile.
 constexpr int XBS = 9;  // padded row stride of the 64 x 8 panel buffer
+#ifndef FT_STAMP
+#define FT_STAMP(i)
+#endif
 __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Zt)[TS], double *Xb, int lane, bool store,
                                             double *__restrict__ Ztile, int nvalid) {
   const int li = lane & 15, lk = lane >> 4;
@@ -852,6 +856,7 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
         acc[rt][ct][q] = (rt < 2) ? tile[row][col] : ((row == col) ? 1.0 : 0.0);
       }
   bool bad = false;
+  FT_STAMP(0);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     // a. panel columns 8p .. 8p+7: C/D layout -> one row per lane
@@ -865,7 +870,32 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
     double bp[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bp[j] = Xb[lane * XBS + j];
+    FT_STAMP(1 + 4 * p);
     // b. elimination inside the panel
+#ifdef MVBA_FACTOR_PAIRS
+    // Two pivots per step: with a = B[k][k], b = B[k+1][k], c = B[k+1][k+1] the two reciprocal roots
+    // 1/l11 = rsq(a) and 1/l22 = rsq(a c - b^2) * l11 do not depend on each other, so the serial chain
+    // (rsq + two Newton steps + broadcast) is walked 16 times per tile instead of 32.  a c - b^2
+    // loses the same digits as the usual c - b^2 / a (both are det / a up to the factor a).
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int r0 = 8 * p + k, r1 = r0 + 1;
+      const double a = readlane_d(bp[k], r0), b = readlane_d(bp[k], r1), c = readlane_d(bp[k + 1], r1);
+      const double det = fma(a, c, -b * b);
+      bad |= !(a > 0.0) | !(det > 0.0);
+      double ra = __builtin_amdgcn_rsq(a), rd = __builtin_amdgcn_rsq(det);
+      ra = ra * (1.5 - 0.5 * a * ra * ra);
+      rd = rd * (1.5 - 0.5 * det * rd * rd);
+      ra = ra * (1.5 - 0.5 * a * ra * ra);
+      rd = rd * (1.5 - 0.5 * det * rd * rd);
+      const double l21 = b * ra, inv22 = rd * (a * ra);
+      bp[k] = bp[k] * ra;
+      bp[k + 1] = (bp[k + 1] - bp[k] * l21) * inv22;
+#pragma unroll
+      for (int j = k + 2; j < 8; ++j)
+        bp[j] -= bp[k] * readlane_d(bp[k], 8 * p + j) + bp[k + 1] * readlane_d(bp[k + 1], 8 * p + j);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const double piv = readlane_d(bp[k], 8 * p + k);
@@ -880,6 +910,8 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
 #pragma unroll
       for (int j = k + 1; j < 8; ++j) bp[j] -= bp[k] * readlane_d(bp[k], 8 * p + j);
     }
+#endif
+    FT_STAMP(2 + 4 * p);
     // c. finished columns back to Xb; rows 32..63 are rows of L^-T
 #pragma unroll
     for (int j = 0; j < 8; ++j) Xb[lane * XBS + j] = bp[j];
@@ -894,6 +926,7 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
     }
     // d. all later columns: acc[rt][ct] -= B[16 rt .., panel] L[16 ct .., panel]^T
     wave_sync();
+    FT_STAMP(3 + 4 * p);
     if (p < 3) {
       double xa[4][2];
 #pragma unroll
@@ -909,15 +942,13 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
             acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[rt][t], xa[ct][t], acc[rt][ct], 0, 0, 0);
       wave_sync();  // the next panel overwrites Xb
     }
+    FT_STAMP(4 + 4 * p);
   }
   return !bad;
 }
 
 __device__ __forceinline__ void chol_super_body(double *lds, double *M, int ld, int D, int jS, double *__restrict__ Ztiles,
-                                                double *__restrict__ Lblk, int *__restrict__ flag, int bid, long long *trace = nullptr) {
-  int nst = 0;
-  auto st = [&](int who) { if (trace && bid == 0 && threadIdx.x == who) { trace[nst] = wall_clock64(); trace[64 + nst] = clock64(); } ++nst; };
-  st(0);
+                                                double *__restrict__ Lblk, int *__restrict__ flag, int bid) {
   double (*T)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);
   double (*Zt)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 10 * NB * TS);
   double (*Pt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 12 * NB * TS);
@@ -959,33 +990,25 @@ __device__ __forceinline__ void chol_super_body(double *lds, double *M, int ld, 
   double v0[P0];
 #pragma unroll
   for (int ps = 0; ps < P0; ++ps) v0[ps] = tile_raw(0, tid + ps * SUPER_THREADS);
-  if (trace && bid == 0 && threadIdx.x == 0) trace[47] = wall_clock64();
   auto store_tile0 = [&]() {
 #pragma unroll
     for (int ps = 0; ps < P0; ++ps) {
       const int idx = tid + ps * SUPER_THREADS;
       if (idx < NB * NB) T[0][idx >> 5][idx & 31] = tile_fix(0, idx, v0[ps]);
     }
-    if (trace && bid == 0 && threadIdx.x == 0) trace[48] = wall_clock64();
     __syncthreads();  // tile (0,0) loaded
   };
   if (wave == 0) {
     // ---- the chain: nothing else to load (its own code path, so that its wait counts only its loads)
     store_tile0();
-    st(0);
     for (int q = 0; q < nq; ++q) {
       // ---- F
       const bool ok = factor_tile(T[tix(q, q)], Zt[q & 1], lds + 12 * NB * TS + 64 * TS, lane, wg0, Ztiles + (size_t)q * NB * NB, nbS - NB * q);
       if (!ok && wg0 && lane == 0) atomicOr(flag, 2);  // not positive definite
-      st(0);
       __syncthreads();  // B1: Zt[q & 1] ready; tiles (r,q), r > q, final
-      st(0);
       __syncthreads();  // B2: X tiles of panel q complete
-      st(0);
       __syncthreads();  // B3: tile (q+1,q+1) final
-      st(0);
     }
-    st(0);
     return;  // (of this inlined body: the caller's code after it still runs)
   }
   // ---- workers (and the idle wave): tile (0,0) first, so that the chain starts after ONE short round
@@ -1161,7 +1184,6 @@ __device__ __forceinline__ void chol_super_body(double *lds, double *M, int ld, 
     mvba_d4 d0, d1;
     own_trsm(nq - 1, d0, d1);
   }
-  if (trace && bid == 0 && threadIdx.x == 64) trace[40] = wall_clock64();
 }
 
 __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *M, int ld, int D, int jS, double *__restrict__ Ztiles,
@@ -1392,12 +1414,9 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double *M, int ld, int D
   chol_backsolve_body(M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, jS, jE, jE2, blockIdx.x, threadIdx.x);
 }
 
-// ---- the whole factor-and-solve as ONE launch: the phases above run back to back inside a persistent
-// grid, separated by device-wide barriers instead of kernel boundaries (a boundary on this chip costs
-// ~10 us of drain + cache write-back + dispatch; 20 of them were most of the 0.5 ms solve at D = 893).
-// Every workgroup runs the same phase sequence and reaches every barrier (the counts depend on D only),
-// the grid is at most one workgroup per CU, and a barrier gives up after ~2^22 polls (flag bit 8 ->
-// MVBA_ERR_HIP on the host) instead of spinning for ever, so the grid always drains.
+// Device-wide barrier of a persistent grid (every workgroup co-resident: at most one per CU).  Every
+// workgroup reaches every barrier (the counts depend on D only), and a barrier gives up after ~2^22
+// polls (flag bit 8 -> MVBA_ERR_HIP on the host) instead of spinning for ever, so the grid always drains.
 __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int *flag) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's global writes are visible device-wide
   __syncthreads();
@@ -1416,175 +1435,124 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // and the other workgroups' writes are visible to this wave
 }
 
-// The phases are CALLED, not inlined: each keeps the register allocation it has as a kernel of its own
-// (inlined into one loop nest the compiler spills ~150 VGPRs).
-__device__ __noinline__ void chol_super_call(double *lds, double *M, int ld, int D, int jS, double *Ztiles, double *Lblk, int *flag,
-                                             int bid, long long *trace) {
-  chol_super_body(lds, M, ld, D, jS, Ztiles, Lblk, flag, bid, trace);
-}
-__device__ __noinline__ void chol_trail_call(double *M, int ld, int D, int jS, int jE, int bx, int by, int wave, int lane) {
-  chol_trail_body(M, ld, D, jS, jE, bx, by, wave, lane);
-}
-__device__ __noinline__ void chol_backsolve_call(double *M, int ld, int D, int m, int gauge_axis, const double *Ztiles,
-                                                 const double *Lblk, double *dxi_full, int jS, int jE, int jE2, int bid, int tid) {
-  chol_backsolve_body(M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, jS, jE, jE2, bid, tid);
-}
-
-__device__ __noinline__ unsigned chol_backsolve_persist(double *lds, double *M, int ld, int D, int m, int gauge_axis,
-                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full, unsigned *bar,
-                                                       unsigned epoch, int *flag, long long *trace);
-
-__global__ __launch_bounds__(SUPER_THREADS) void k_chol_persist(double *M, int ld, int D, int m, int gauge_axis, double *Ztiles,
-                                                                double *Lblk, double *dxi_full, int *flag, unsigned *bar,
-                                                                long long *trace) {
+// ---- L^T x = y for all super-blocks in ONE persistent launch (last block first), S - 1 device-wide
+// barriers instead of S launches.  Step s (x_{s+1} known):
+//   workgroup s ("chain" of block s)
+//       y_s -= (rows of the block above)^T x_{s+1}; then the block's four tiles from the bottom:
+//       x_t = Z_t y_t (Z = L_tt^-T from the factorisation), y_{t' < t} -= L[t][t']^T x_t.
+//       Everything static it needs (Z tiles and in-block L tiles -> LDS, the 128 x 128 panel below the
+//       block -> registers: 208 KiB, ~10 us for one CU) is loaded when the kernel starts, by all S chain
+//       workgroups at once; at its step a chain workgroup reads only x_{s+1} and y_s (2 KiB).
+//   workgroups >= S ("bulk")
+//       y[c] -= (rows of block s+1)^T x_{s+1} for the columns left of block s, 32 columns x 8 row
+//       chunks per workgroup: one batch of 16 loads per thread, LDS reduction.
+// One barrier per step: x_s must reach the next chain and the bulk workgroups, their updates the chain.
+__global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M, int ld, int D, int m, int gauge_axis,
+                                                                      const double *Ztiles, const double *Lblk_all, double *dxi_full,
+                                                                      int *flag, unsigned *bar) {
   extern __shared__ double lds[];
-  const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  unsigned epoch = 0;
-  int nstamp = 0;
-  auto stamp = [&]() {  // MVBA_CHOL_TRACE: workgroup 0's 100 MHz clock at every phase boundary
-    if (trace && bid == 0 && tid == 0) trace[nstamp] = wall_clock64();
-    ++nstamp;
-  };
-  stamp();
-  for (int jS = 0; jS < D; jS += SBW) {
-    const int jE = min(jS + SBW, D), nsup = (D + 1 - jE + 63) / 64;
-    for (int b = bid; b < nsup; b += G) {
-      chol_super_call(lds, M, ld, D, jS, Ztiles + (size_t)(jS / NB) * NB * NB, Lblk + (size_t)(jS / SBW) * SBW * SBW, flag, b,
-                      (trace && jS == SBW) ? trace + 128 : nullptr);
-      __syncthreads();  // (only when one workgroup serves several row groups: LDS is reused)
-    }
-    stamp();
-    grid_barrier(bar, ++epoch * G, flag);
-    stamp();
-    if (jE < D) {
-      // lower triangle of the nsup x nsup grid of 64 x 64 tiles, one wave per 32 x 32 quadrant
-      const int ntile = nsup * (nsup + 1) / 2;
-      if (wave < 4)
-        for (int t = bid; t < ntile; t += G) {
-          int by = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-          while (by * (by + 1) / 2 > t) --by;
-          while ((by + 1) * (by + 2) / 2 <= t) ++by;
-          chol_trail_call(M, ld, D, jS, jE, t - by * (by + 1) / 2, by, wave, lane);
-        }
-      stamp();
-      grid_barrier(bar, ++epoch * G, flag);
-      stamp();
-    }
-  }
-  chol_backsolve_persist(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, bar, epoch, flag, trace ? trace + 256 : nullptr);
-}
-
-// ---- L^T x = y for all super-blocks in one persistent pass (last block first).  Per step s:
-//   workgroup 0 ("chain")  y_s -= (rows of the block above)^T x_{s+1}; then the block's four tiles from the
-//                          bottom: x_t = Z_t y_t (Z = L_tt^-T from the factorisation), y_{t' < t} -= L[t][t']^T x_t.
-//                          Everything static it needs (Z tiles, the in-block L tiles, the 128 x 128 panel of the
-//                          block above) is requested in ONE batch at the start of the step together with y_s, the
-//                          tile chain then runs out of LDS and registers.
-//   workgroups >= 1        y[c] -= (rows of block s+1)^T x_{s+1} for the columns left of block s, 32 columns x
-//                          8 row chunks per workgroup: one batch of 16 loads per thread, LDS reduction.
-// One device-wide barrier per step (x_s must reach the other workgroups, their updates the chain).
-__device__ __forceinline__ unsigned chol_backsolve_persist_body(double *lds, double *M, int ld, int D, int m, int gauge_axis,
-                                                                const double *Ztiles, const double *Lblk_all, double *dxi_full,
-                                                                unsigned *bar, unsigned epoch, int *flag, long long *trace) {
   const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool act = tid < 256;
   double *y = M + (size_t)D * ld;
   const int S = (D + SBW - 1) / SBW;
   double (*Zs)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);                // [4]
   double (*Ls)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 4 * NB * TS);  // [6]: in-block tile (r, c < r) at r (r - 1) / 2 + c
-  double *ys = lds + 10 * NB * TS, *xp = ys + SBW, *part = xp + SBW;               // part[3][SBW]; bulk: red[8][32]
-  int nst = 0;
-  auto st = [&]() { if (trace && bid == 0 && tid == 0) trace[nst] = wall_clock64(); ++nst; };
-  if (bid == 0) {
-    if (act)
-      for (int i = tid; i < 9 * m; i += 256) dxi_full[i] = 0.0;  // the gauge slots stay zero
-    if (tid < SBW) xp[tid] = 0.0;
-  }
-  for (int s = S - 1; s >= 0; --s) {
-    const int jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), ns = jE - jS, np = jE2 - jE;
-    st();
-    if (bid == 0) {
-      // ---- one batch of loads (all SUPER_THREADS threads).  Every load is "uniform base + one per-thread
-      // offset", so the addresses live in SGPRs and the batch fits the register file without spills.
-      const double *Lblk = Lblk_all + (size_t)s * SBW * SBW;
-      constexpr int NT = SUPER_THREADS, NPASS = (NB * NB + NT - 1) / NT, NPN = (SBW + 2) / 3;
-      double zl[10][NPASS], pn[NPN];
+  double *ys = lds + 10 * NB * TS, *part = ys + SBW;                               // part[3][SBW]; bulk: red[8][32]
+  unsigned epoch = 0;
+  if (bid < S) {
+    // ================= chain of block s = bid
+    const int s = bid, jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), ns = jE - jS, np = jE2 - jE;
+    // ---- static operands, one batch.  Every load is "uniform base + one per-thread offset", so the
+    // addresses live in SGPRs and the batch fits the register file.
+    const double *Lblk = Lblk_all + (size_t)s * SBW * SBW;
+    constexpr int NT = SUPER_THREADS, NPASS = (NB * NB + NT - 1) / NT, NPN = (SBW + 2) / 3;
+    double zl[10][NPASS], pn[NPN];
 #pragma unroll
-      for (int tile = 0; tile < 10; ++tile) {
-        // tiles 0..3: Z (upper triangle of L_tt^-T); 4..9: in-block L tile (tr, tc < tr)
-        const int e = tile - 4, tr = (e >= 3) ? 3 : (e >= 1) ? 2 : 1, tc = e - tr * (tr - 1) / 2;
-        const double *base = (tile < 4) ? Ztiles + (size_t)(jS / NB + tile) * NB * NB : Lblk + (size_t)(NB * tr) * SBW + NB * tc;
-        const int nb = ns - NB * (tile < 4 ? tile : tr);  // valid rows (and columns, for Z) of the tile
+    for (int tile = 0; tile < 10; ++tile) {
+      // tiles 0..3: Z (upper triangle of L_tt^-T); 4..9: in-block L tile (tr, tc < tr)
+      const int e = tile - 4, tr = (e >= 3) ? 3 : (e >= 1) ? 2 : 1, tc = e - tr * (tr - 1) / 2;
+      const double *base = (tile < 4) ? Ztiles + (size_t)(jS / NB + tile) * NB * NB : Lblk + (size_t)(NB * tr) * SBW + NB * tc;
+      const int nb = ns - NB * (tile < 4 ? tile : tr);  // valid rows (and columns, for Z) of the tile
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-          const int w = tid + NT * ps, r = w >> 5, c = w & 31;
-          const bool ok = w < NB * NB && r < nb && (tile >= 4 || (c >= r && c < nb));
-          zl[tile][ps] = ok ? base[tile < 4 ? w : r * SBW + c] : 0.0;
-        }
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int w = tid + NT * ps, r = w >> 5, c = w & 31;
+        const bool ok = w < NB * NB && r < nb && (tile >= 4 || (c >= r && c < nb));
+        zl[tile][ps] = ok ? base[tile < 4 ? w : r * SBW + c] : 0.0;
       }
-      const int pc = tid & (SBW - 1), ph = tid >> 7;  // three threads per column, every third row
-      const int poff = ph * ld + pc;
+    }
+    const int pc = tid & (SBW - 1), ph = tid >> 7;  // three threads per column, every third row
+    const int poff = ph * ld + pc;
 #pragma unroll
-      for (int i = 0; i < NPN; ++i) {
-        const double *rowbase = M + (size_t)(jE + 3 * i) * ld + jS;  // uniform
-        pn[i] = (pc < ns && ph + 3 * i < np) ? rowbase[poff] : 0.0;
+    for (int i = 0; i < NPN; ++i) {
+      const double *rowbase = M + (size_t)(jE + 3 * i) * ld + jS;  // uniform
+      pn[i] = (pc < ns && ph + 3 * i < np) ? rowbase[poff] : 0.0;
+    }
+#pragma unroll
+    for (int tile = 0; tile < 10; ++tile)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int w = tid + NT * ps;
+        if (w < NB * NB) Zs[tile][w >> 5][w & 31] = zl[tile][ps];  // Ls follows Zs: tile 4 + e lands in Ls[e]
       }
-      const double yv = (tid < ns) ? y[jS + tid] : 0.0;
-      // ---- to LDS; the block above's share of y_s
+    // ---- wait for the step
+    for (int t = S - 1; t > s; --t) grid_barrier(bar, ++epoch * G, flag);
+    // x_{s+1} (published by chain s+1 before the barrier) and y_s (complete but for the panel's share)
+    const double yv = (tid < ns) ? y[jS + tid] : 0.0;
+    double sa = 0.0, sb = 0.0;
+    if (np > 0) {
+      double xv[NPN];
 #pragma unroll
-      for (int tile = 0; tile < 10; ++tile)
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-          const int w = tid + NT * ps;
-          if (w < NB * NB) Zs[tile][w >> 5][w & 31] = zl[tile][ps];  // Ls follows Zs: tile 4 + e lands in Ls[e]
-        }
-      double sa = 0.0, sb = 0.0;
+      for (int i = 0; i < NPN; ++i) xv[i] = (ph + 3 * i < np) ? y[jE + ph + 3 * i] : 0.0;
 #pragma unroll
       for (int i = 0; i + 1 < NPN; i += 2) {
-        sa += pn[i] * xp[ph + 3 * i];
-        sb += pn[i + 1] * xp[ph + 3 * i + 3];
+        sa += pn[i] * xv[i];
+        sb += pn[i + 1] * xv[i + 1];
       }
-      if (NPN & 1) sa += pn[NPN - 1] * xp[min(ph + 3 * (NPN - 1), SBW - 1)];  // (pn = 0 when that row does not exist)
-      part[ph * SBW + pc] = sa + sb;
-      __syncthreads();
-      if (tid < SBW) ys[tid] = (tid < ns) ? yv - part[tid] - part[SBW + tid] - part[2 * SBW + tid] : 0.0;
-      __syncthreads();
-      st();
-      // ---- the tile chain
-      for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
-        if (wave == 0) {
-          const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
-          double s0 = 0.0, s1 = 0.0;
+      if (NPN & 1) sa += pn[NPN - 1] * xv[NPN - 1];
+    }
+    part[ph * SBW + pc] = sa + sb;
+    __syncthreads();
+    if (tid < SBW) ys[tid] = (tid < ns) ? yv - part[tid] - part[SBW + tid] - part[2 * SBW + tid] : 0.0;
+    __syncthreads();
+    // ---- the tile chain
+    for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
+      if (wave == 0) {
+        const int r = lane & 31, h = lane >> 5;  // two lanes per row, 16 columns each
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int q = 0; q < NB / 2; q += 2) {
-            s0 += Zs[t][r][16 * h + q] * ys[t * NB + 16 * h + q];
-            s1 += Zs[t][r][16 * h + q + 1] * ys[t * NB + 16 * h + q + 1];
-          }
-          double xr = s0 + s1;
-          xr += __shfl_xor(xr, 32, 64);
-          if (lane < NB) ys[t * NB + lane] = xr;  // rows beyond the block's end: Zs row = 0 -> 0
+        for (int q = 0; q < NB / 2; q += 2) {
+          s0 += Zs[t][r][16 * h + q] * ys[t * NB + 16 * h + q];
+          s1 += Zs[t][r][16 * h + q + 1] * ys[t * NB + 16 * h + q + 1];
         }
-        __syncthreads();
-        if (tid < t * NB) {
-          const double (*Lt)[TS] = Ls[t * (t - 1) / 2 + (tid >> 5)];
-          double sacc = 0.0;
+        double xr = s0 + s1;
+        xr += __shfl_xor(xr, 32, 64);
+        if (lane < NB) ys[t * NB + lane] = xr;  // rows beyond the block's end: Zs row = 0 -> 0
+      }
+      __syncthreads();
+      if (tid < t * NB) {
+        const double (*Lt)[TS] = Ls[t * (t - 1) / 2 + (tid >> 5)];
+        double sacc = 0.0;
 #pragma unroll
-          for (int r = 0; r < NB; ++r) sacc += Lt[r][tid & 31] * ys[t * NB + r];
-          ys[tid] -= sacc;
-        }
-        __syncthreads();
+        for (int r = 0; r < NB; ++r) sacc += Lt[r][tid & 31] * ys[t * NB + r];
+        ys[tid] -= sacc;
       }
-      if (tid < SBW) xp[tid] = ys[tid];  // x_s: the next step's "block above"
-      if (tid < ns) {
-        y[jS + tid] = ys[tid];
-        dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
-      }
-      st();
-    } else if (np > 0) {
-      // ---- bulk: columns left of block s, rows of block s+1
-      double *red = part;
-      const int cj = tid & 31, ch = tid >> 5, ngrp = (jS + 31) / 32;
-      for (int g = bid - 1; g < ngrp; g += G - 1) {
+      __syncthreads();
+    }
+    if (tid < ns) {
+      y[jS + tid] = ys[tid];
+      dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
+    }
+    if (s == 0 && tid < 7) dxi_full[tid < 6 ? 3 + tid : 12 + gauge_axis] = 0.0;  // the removed (gauge) parameters
+    for (int t = s; t > 0; --t) grid_barrier(bar, ++epoch * G, flag);
+    return;
+  }
+  // ================= bulk: at step s, columns left of block s, rows of block s+1
+  const bool act = tid < 256;
+  double *red = part;
+  const int cj = tid & 31, ch = tid >> 5, nbulk = G - S;
+  for (int s = S - 1; s >= 0; --s) {
+    const int jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), np = jE2 - jE, ngrp = (jS + 31) / 32;
+    if (np > 0)
+      for (int g = bid - S; g < ngrp; g += nbulk) {
         const int c = 32 * g + cj;
         double lv[16], xv[16];
 #pragma unroll
@@ -1611,24 +1579,8 @@ __device__ __forceinline__ unsigned chol_backsolve_persist_body(double *lds, dou
         }
         __syncthreads();
       }
-    }
     if (s > 0) grid_barrier(bar, ++epoch * G, flag);
   }
-  st();
-  return epoch;
-}
-
-__global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M, int ld, int D, int m, int gauge_axis,
-                                                                      const double *Ztiles, const double *Lblk, double *dxi_full,
-                                                                      int *flag, unsigned *bar, long long *trace) {
-  extern __shared__ double lds[];
-  chol_backsolve_persist_body(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk, dxi_full, bar, 0u, flag, trace);
-}
-
-__device__ __noinline__ unsigned chol_backsolve_persist(double *lds, double *M, int ld, int D, int m, int gauge_axis,
-                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full, unsigned *bar,
-                                                       unsigned epoch, int *flag, long long *trace) {
-  return chol_backsolve_persist_body(lds, M, ld, D, m, gauge_axis, Ztiles, Lblk_all, dxi_full, bar, epoch, flag, trace);
 }
 
 // ---- fallback: LU with partial pivoting (what np.linalg.solve / LAPACK gesv does, ref :146) ----
@@ -1936,8 +1888,8 @@ struct mvba_handle {
   int n_partials = 0, cost_grid = 0;
   int *d_flag = nullptr, *h_flag = nullptr;
   unsigned *d_bar = nullptr;
-  long long *d_trace = nullptr;
-  int chol_mode = 1, chol_grid = 1, chol_grid_max = 1;  // 0: one launch per phase, 1: persistent grid, 2: persistent grid, cooperative launch
+  int n_cu = 1;
+  bool chol_onepass = true;  // L^T x = y as one persistent launch (MVBA_CHOL=launches: one launch per super-block)
   // comm
   ncclComm_t comm = nullptr;
   mvba_host_allreduce_fn host_ar = nullptr;  // host-staged transport (mvba_comm_init_host) instead of RCCL
@@ -2382,20 +2334,13 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
   {
-    // persistent solve: one workgroup per CU at most (its LDS fills a CU), enough of them for the widest phase
-    int ncu = 0, per_cu = 0;
-    TRYH(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
-    TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_persist, SUPER_THREADS, SUPER_LDS));
-    const int nsup0 = (h->D + 1 - std::min(SBW, h->D) + 63) / 64;
-    h->chol_grid_max = ncu;
-    h->chol_grid = std::max(h->D > SBW ? 2 : 1, std::min(ncu, std::max(nsup0, nsup0 * (nsup0 + 1) / 2)));
-    h->chol_mode = per_cu >= 1 ? 3 : 0;
-    if (const char *ev = getenv("MVBA_CHOL"))
-      h->chol_mode = !strcmp(ev, "launches") ? 0 : !strcmp(ev, "persist") ? 1 : !strcmp(ev, "coop") ? 2 : !strcmp(ev, "hybrid") ? 3 : h->chol_mode;
-    if (const char *ev = getenv("MVBA_CHOL_GRID")) h->chol_grid = std::max(1, std::min(ncu, atoi(ev)));
+    // the persistent back-substitution needs its whole grid resident: at most one workgroup per CU
+    int per_cu = 0;
+    TRYH(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_backsolve_all, SUPER_THREADS, BACKSOLVE_LDS));
+    h->chol_onepass = per_cu >= 1 && !(getenv("MVBA_CHOL") && !strcmp(getenv("MVBA_CHOL"), "launches"));
   }
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
@@ -2414,7 +2359,7 @@ void mvba_destroy(mvba_handle *h) {
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
-                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_trace};
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_allcost) hipHostFree(h->h_allcost);
@@ -2568,61 +2513,30 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int ld = h->ld;
     hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
                        h->d_Ared, h->d_bar);
-    if (h->chol_mode == 1 || h->chol_mode == 2) {  // one persistent launch (see k_chol_persist)
-      static const bool trace_on = getenv("MVBA_CHOL_TRACE") != nullptr;
-      if (trace_on && !h->d_trace) MVBA_HIP(hipMalloc(&h->d_trace, 1024 * sizeof(long long)));
-      void *args[] = {&h->d_Ared, (void *)&ld, (void *)&D, (void *)&m, &h->gauge_axis, &h->d_Ztiles, &h->d_Lblk, &h->d_dxi, &h->d_flag, &h->d_bar, &h->d_trace};
-      if (h->chol_mode == 2)
-        MVBA_HIP(hipLaunchCooperativeKernel((const void *)k_chol_persist, dim3(h->chol_grid), dim3(SUPER_THREADS), args, SUPER_LDS, h->stream));
-      else
-        hipLaunchKernelGGL(k_chol_persist, dim3(h->chol_grid), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, m,
-                           h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->d_trace);
-      if (trace_on) {  // debugging aid: phase times of workgroup 0, in microseconds
-        std::vector<long long> ts(1024);
-        MVBA_HIP(hipStreamSynchronize(h->stream));
-        MVBA_HIP(hipMemcpy(ts.data(), h->d_trace, sizeof(long long) * 1024, hipMemcpyDeviceToHost));
-        const int S = (D + SBW - 1) / SBW, n = 1 + 2 * S + 2 * (S - 1) + 2 * S;
-        fprintf(stderr, "chol trace (us):");
-        for (int i = 1; i < n; ++i) fprintf(stderr, " %.1f", (ts[i] - ts[i - 1]) * 0.01);
-        fprintf(stderr, "  total %.1f\n", (ts[n - 1] - ts[0]) * 0.01);
-        fprintf(stderr, "super-block 1 chain wave (us from entry):");
-        for (int i = 1; i < 19; ++i) fprintf(stderr, " %.1f", (ts[128 + i] - ts[128]) * 0.01);
-        fprintf(stderr, "  workers done %.1f; tile(0,0): requested %.2f, stored %.2f\n", (ts[128 + 40] - ts[128]) * 0.01,
-                (ts[128 + 47] - ts[128]) * 0.01, (ts[128 + 48] - ts[128]) * 0.01);
-        fprintf(stderr, "back-substitution steps (us: loads+panel, chain, publish+barrier):");
-        for (int i2 = 0; i2 < (D + SBW - 1) / SBW; ++i2)
-          fprintf(stderr, " [%.1f %.1f %.1f]", (ts[256 + 3 * i2 + 1] - ts[256 + 3 * i2]) * 0.01, (ts[256 + 3 * i2 + 2] - ts[256 + 3 * i2 + 1]) * 0.01,
-                  (ts[256 + 3 * i2 + 3] - ts[256 + 3 * i2 + 2]) * 0.01);
-        fprintf(stderr, "\n");
-        fprintf(stderr, "same in clock64 ticks:");
-        for (int i = 1; i < 19; ++i) fprintf(stderr, " %lld", ts[128 + 64 + i] - ts[128 + 64]);
-        fprintf(stderr, "\n");
-      }
-    } else {
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
       hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
                          h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
         const int nt = (D + 1 - jE + 63) / 64, nt32 = (D + 1 - jE + NB - 1) / NB;
-        static const int small_max = getenv("MVBA_TRAIL32_MAX") ? atoi(getenv("MVBA_TRAIL32_MAX")) : 2 * h->chol_grid_max;
+        static const int small_max = getenv("MVBA_TRAIL32_MAX") ? atoi(getenv("MVBA_TRAIL32_MAX")) : 2 * h->n_cu;
         if (nt * (nt + 1) / 2 <= small_max)
           hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
         else
           hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
-    if (h->chol_mode == 3) {  // launches for the factorisation, one persistent pass for L^T x = y
-      const int ngrp = (((D - 1) / SBW) * SBW + 31) / 32;
-      hipLaunchKernelGGL(k_chol_backsolve_all, dim3(std::min(h->chol_grid_max, 1 + ngrp)), dim3(SUPER_THREADS), SUPER_LDS, h->stream,
-                         h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->d_trace);
+    const int S = (D + SBW - 1) / SBW;
+    if (h->chol_onepass && (S == 1 || S < h->n_cu)) {  // one persistent pass for L^T x = y (see k_chol_backsolve_all)
+      const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(h->n_cu - S, ngrp)) : 0;
+      hipLaunchKernelGGL(k_chol_backsolve_all, dim3(S + nbulk), dim3(SUPER_THREADS), BACKSOLVE_LDS, h->stream, h->d_Ared, ld, D, m,
+                         h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar);
     } else
     for (int jS = ((D - 1) / SBW) * SBW; jS >= 0; jS -= SBW) {
       const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
       const int nwg = (jE == D) ? 1 : 1 + (jS + 255) / 256;
       hipLaunchKernelGGL(k_chol_backsolve, dim3(nwg), dim3(256), 0, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles,
                          h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_dxi, jS, jE, jE2);
-    }
     }
   }
   MVBA_HIP(hipGetLastError());
@@ -2673,7 +2587,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (*h->h_flag) {
     const int fl = *h->h_flag;
     hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
-    if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_persist: a device-wide barrier timed out (is another process holding the CUs?)");
+    if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_backsolve_all: a device-wide barrier timed out (is another process holding the CUs?)");
     return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system)");
   }
   h->have_trial = true;
