@@ -1687,12 +1687,11 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 
 // ------------------------------------------------------------------ K5
 // dX_a = -E_a^-1 (sum_o F_ao dxi_k + dP_a), X' = X + dX  (ref :152, :260-261).  Eight lanes per
-// point, one observation per lane.  The Jacobian rows of an observation are RECOMPUTED from the
-// committed point and the committed camera (LDS table) with the very function K1 used, instead of
-// re-reading the 128-byte records: the kernel then moves 24 B/point + 4 B/observation instead of
-// 128 B/observation (1.7 GB -> 0.25 GB at config 3) for ~150 fp64 operations per observation, which
-// the chip has to spare.  y_o = 2 Jx^T (Jc dxi_k) with the implied columns of the record form
-// ((u,v) -> 1/f0, t -> -J_X), so that it is the same linear map the Schur kernel assembled.
+// point, one observation per lane.  y_o = 2 Jx^T (Jc dxi_k) is RECOMPUTED from the committed point
+// and the committed camera (LDS table) instead of re-reading the 128-byte records: the kernel then
+// moves 24 B/point + 4 B/observation instead of 128 B/observation (1.7 GB -> 0.25 GB at config 3),
+// and it is evaluated as a directional derivative (obs_backsub: ~75 fp64 operations, the Jacobian rows
+// are never formed) -- the same linear map the Schur kernel assembled, implied columns included.
 // The trial cost is k_cost on the trial state (K6).
 __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
                                                  const int *__restrict__ cam_idx, const double *__restrict__ PB,
@@ -1706,7 +1705,6 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
   __syncthreads();
   constexpr int G = 4;  // lanes per point
   const int s = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-  const double cu = 1.0 / f0;
   const long long a_first = (long long)blockIdx.x * (256 / G) + grp, a_step = (long long)gridDim.x * (256 / G);
   long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
   if (a_first < npts) { nx0 = pt_ptr[a_first]; nx1 = pt_ptr[a_first + 1]; }
@@ -1720,16 +1718,11 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     for (long long o = o0 + s; o < o1; o += G) {
       const int k = cam_idx[o];
-      const double *dk = s_dxi + 9 * k;
-      ObsJ J;
-      obs_math(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, 0.0, 0.0, f0, J);
-      const double s0 = J.jc[0][0] * dk[0] + cu * dk[1] - (J.jx[0][0] * dk[3] + J.jx[0][1] * dk[4] + J.jx[0][2] * dk[5]) +
-                        (J.jc[0][6] * dk[6] + J.jc[0][7] * dk[7] + J.jc[0][8] * dk[8]);
-      const double s1 = J.jc[1][0] * dk[0] + cu * dk[2] - (J.jx[1][0] * dk[3] + J.jx[1][1] * dk[4] + J.jx[1][2] * dk[5]) +
-                        (J.jc[1][6] * dk[6] + J.jc[1][7] * dk[7] + J.jc[1][8] * dk[8]);
-      y0 += 2.0 * (J.jx[0][0] * s0 + J.jx[1][0] * s1);
-      y1 += 2.0 * (J.jx[0][1] * s0 + J.jx[1][1] * s1);
-      y2 += 2.0 * (J.jx[0][2] * s0 + J.jx[1][2] * s1);
+      double t0, t1, t2;
+      obs_backsub(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, s_dxi + 9 * k, f0, t0, t1, t2);
+      y0 += t0;
+      y1 += t1;
+      y2 += t2;
     }
 #pragma unroll
     for (int msk = 1; msk < G; msk <<= 1) {  // fixed butterfly: every lane ends with the group sum
