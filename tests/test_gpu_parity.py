@@ -376,6 +376,36 @@ def test_config4_shape_500_cameras_8_virtual_shards():
     np.testing.assert_allclose(As, Af, rtol=0, atol=1e-12 * np.abs(Af).max())
 
 
+@pytest.mark.parametrize("n,m,p", [(600, 9, 0.6), (3000, 50, 0.3), (900, 300, 0.06)])
+def test_dense_solve_variants_agree(n, m, p, monkeypatch):
+    """The dense solve has two back-substitutions (one persistent launch with device-wide barriers, or
+    one launch per super-block behind MVBA_CHOL=launches) and two trailing-update kernels (32 x 32 tiles
+    while the trailing matrix is small, 64 x 64 above: MVBA_TRAIL32_MAX moves the switch).  All
+    combinations must give the camera step of the oracle's solve (D = 74, 443, 2693)."""
+    sc = make_scene(n, m, vis_p=p)
+    g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
+    g.linearize()
+    c = 1e-3
+    g.try_step(c)
+    ref = np.zeros(9 * m)
+    ref[g.keep] = g.dxi_red
+    got = {}
+    for mode in ("default", "launches"):
+        if mode == "launches":
+            monkeypatch.setenv("MVBA_CHOL", "launches")
+        ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                              sc.init_R, sc.init_t, axis=sc.axis)
+        eng = ba._engine
+        eng.linearize()
+        eng.try_step(c)
+        got[mode] = eng.debug_read("dxi")
+        assert eng.stats()["counts"]["lu_fallback"] == 0
+        np.testing.assert_allclose(got[mode], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(got["launches"], got["default"], rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n,m,p", [(3000, 14, 0.5), (900, 300, 0.06)])
 def test_strip_schur_kernels_match_the_oracle(n, m, p, monkeypatch):
     """The camera-strip Schur kernel (round 1's K3, kept behind MVBA_SCHUR=strip as an independent
