@@ -669,20 +669,22 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
   }
 }
 
-template <int WPB>  // waves per block (each wave works alone; a block only shares its launch and its LDS allocation)
-__global__ __launch_bounds__(64 * WPB, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
-                                                        const int *__restrict__ q_units, int *__restrict__ head,
-                                                        const int *__restrict__ it_k, const int *__restrict__ it_l,
-                                                        const int *__restrict__ it_a, const double2 *__restrict__ rec,
-                                                        const double *__restrict__ PB, double c, double f0,
-                                                        double *__restrict__ partial) {
+// One wave per block: a wave works alone, and in a wider block its LDS and wave slots stay taken until
+// the block's slowest wave has finished (4 waves per block: 1.945 ms, 2: 1.92, 1: 1.89 at config 3).
+__global__ __launch_bounds__(64, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
+                                                       const int *__restrict__ q_units, int *__restrict__ head,
+                                                       const int *__restrict__ it_k, const int *__restrict__ it_l,
+                                                       const int *__restrict__ it_a, const double2 *__restrict__ rec,
+                                                       const double *__restrict__ PB, double c, double f0,
+                                                       double *__restrict__ partial) {
   extern __shared__ char smem_pairs[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  char *wbuf = smem_pairs + w * (2 * PWAVE_LDS);
-  // ---- take one unit.  Dynamic (default): own XCD's queue first, then the others (every queue entry is
-  // taken exactly once: the grid has as many waves as there are units, and a wave takes at most
-  // one).  Static (head == nullptr; WPB = 1): block b takes entry b / 8 of queue b % 8 -- no atomic on
-  // the critical path, relies on the round-robin block -> XCD placement for locality only.
+  const int lane = threadIdx.x;
+  char *wbuf = smem_pairs;
+  // ---- take one unit.  Static (default, head == nullptr): block b takes entry b / 8 of queue b % 8 -- no
+  // atomic on the critical path; it relies on the round-robin block -> XCD placement for locality
+  // only, never for correctness (1.90 -> 1.87 ms).  Dynamic (MVBA_PAIR_STATIC=0): own XCD's queue
+  // first (XCC_ID), then the others; every queue entry is taken exactly once, the grid has as many
+  // waves as there are units and a wave takes at most one.
   int pos = -1;
   if (!head) {
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -2466,17 +2468,10 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (h->use_pairs) {
     Timed t(h, MVBA_K_SCHUR);
     if (h->n_units) {
-      static const int wpb = getenv("MVBA_PAIR_WPB") ? atoi(getenv("MVBA_PAIR_WPB")) : 1;  // experiment knobs
-      static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));
-      auto launch = [&](auto kern, int W) {
-        const bool st = stat && W == 1;
-        hipLaunchKernelGGL(kern, dim3(st ? 8 * h->q_max : (h->n_units + W - 1) / W), dim3(64 * W), W * 2 * PWAVE_LDS, h->stream,
-                           h->d_units, h->d_q_ptr, h->d_q_units, st ? nullptr : h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec,
-                           h->d_PB, c, h->f0, h->d_partial);
-      };
-      if (wpb == 1) launch(k_schur_pairs<1>, 1);
-      else if (wpb == 2) launch(k_schur_pairs<2>, 2);
-      else launch(k_schur_pairs<4>, 4);
+      static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));  // experiment knob
+      hipLaunchKernelGGL(k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64), 2 * PWAVE_LDS, h->stream, h->d_units,
+                         h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c,
+                         h->f0, h->d_partial);
     }
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,
                        h->d_partial, d_A, d_b, h->d_q_head);
