@@ -2008,7 +2008,7 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
 
 extern "C" {
 
-const char *mvba_version(void) { return "mvba 0.1 (gfx950)"; }
+const char *mvba_version(void) { return "mvba 0.2 (gfx950)"; }
 const char *mvba_last_error(void) { return g_err.c_str(); }
 const char *mvba_kernel_name(int32_t k) { return (k >= 0 && k < MVBA_K_COUNT) ? kKernelNames[k] : ""; }
 
