@@ -7,7 +7,7 @@
 //   K3a k_point_inv      damped 3x3 inverse, v_a = E^-1 dP_a                  (ref :120-128)
 //   K3  k_schur_strip    A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
 //   C1  ncclAllReduce    [A|b] across point shards                            
-//   K4  k_chol_super / k_chol_trail / k_chol_backsolve (+ k_lu_solve rescue)
+//   K4  k_chol_super / k_chol_trail32 / k_chol_backsolve_all (+ k_lu_solve rescue)
 //                        dense solve of the gauge-reduced system              (ref :146)
 //   K5+K6 k_backsub, k_cost  dX_a, trial state, trial cost                    (ref :152-162, :260-281, :666-677)
 // HBM layout: observations sorted by point (CSR).  The linearisation of ONE
@@ -763,9 +763,9 @@ __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restri
 //                 factors the 128x128 diagonal block in LDS (wave 0: tile factorisations in
 //                 registers, identity rows alongside give L^-T) and solves its own rows with
 //                 f64 MFMA (left-looking inside the super-block)
-//   k_chol_trail  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
+//   k_chol_trail32  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
 //                 everything right of the super-block
-// then k_chol_backsolve does L^T x = y per super-block from the L^-T tiles.
+// then k_chol_backsolve_all does L^T x = y, last super-block first, from the L^-T tiles.
 constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 
@@ -797,14 +797,7 @@ typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 // MFMA operands straight from row-major rows: the product sums over k, so any permutation of k
 // that A and B share is allowed.  Lane (idx = l & 15, kq = l >> 4) loads the 4 CONSECUTIVE
 // doubles X[idx][16 g + 4 kq .. + 3] (one 32-byte load; a row's 16-column group is one full
-// 128-byte line across kq) and feeds element u to MFMA step 4 g + u.
-// The load itself is UNCONDITIONAL (callers clamp p into the matrix): a load under a data-dependent
-// branch makes hipcc drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at the branch, which
-// turns a batch of independent loads into a chain of round trips.
-__device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
-  const mvba_d4 v = *reinterpret_cast<const mvba_d4 *>(p);
-  return live ? v : mvba_d4{0.0, 0.0, 0.0, 0.0};
-}
+// 128-byte line across kq) and feeds element u to MFMA step 4 g + u (k_chol_trail32).
 
 // One launch per 128-column super-block [jS, jE).  Workgroup = 5 waves: wave 0 runs the serial
 // chain (the four 32x32 tile factorisations), waves 1..4 ("workers", 16 rows each) own 64 rows
@@ -824,7 +817,7 @@ __device__ __forceinline__ mvba_d4 load_k4(const double *p, bool live) {
 // and the L^-T tiles (Ztiles) for the back-substitution to their OWN buffers: the diagonal block
 // of M is never written, because other workgroups may still be loading it.
 // MFMA layouts: A/B lane l holds X[idx = l & 15][k = 16 g + 4 (l >> 4) + u] at step (g, u)
-// (the k-permutation of load_k4); C/D: col = l & 15, row = (l >> 4) + 4 reg.
+// (the k-permutation above); C/D: col = l & 15, row = (l >> 4) + 4 reg.
 constexpr int TS = NB + 1;                               // padded LDS tile row stride
 constexpr int SUPER_THREADS = 384;  // waves 0..5: chain, workers 0..2, an idle wave (keeps the chain alone on its SIMD), worker 3
 constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS + 64 * 9) * 8;  // 10 tiles + 2 Zt + Pt + panel buffer, bytes
@@ -1195,64 +1188,12 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_super(double *M, int ld,
 }
 
 // Trailing update with f64 MFMA for the finished super-block [jS, jE): C -= P P^T on rows/cols
-// >= jE (jE - jS == SBW).  Block = 4 waves = 64x64 output tile, wave = 32x32.
-__device__ __forceinline__ void chol_trail_body(double *M, int ld, int D, int jS, int jE, int bx, int by, int wave, int lane) {
-  const int r0 = jE + by * 64 + (wave >> 1) * 32;
-  const int c0 = jE + bx * 64 + (wave & 1) * 32;
-  if (c0 > r0 + 31 || r0 > D || c0 >= D) return;  // strictly upper tile or out of range
-  mvba_d4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
-  const int li = lane & 15, lk = lane >> 4;
-  // jE - jS == SBW, consumed in two halves of 64 columns: all 16 loads of a half are issued before
-  // its first MFMA (two memory latencies per wave, ~170 VGPRs -> 3 waves per SIMD hide them)
-  const double *pa[2], *pb[2];
-  bool la[2], lb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rr = r0 + 16 * i + li, cc = c0 + 16 * i + li;
-    la[i] = rr <= D;
-    lb[i] = cc < D;
-    pa[i] = M + (size_t)min(rr, D) * ld + jS + 4 * lk;
-    pb[i] = M + (size_t)min(cc, D) * ld + jS + 4 * lk;
-  }
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    mvba_d4 av[SBW / 32][2], bv[SBW / 32][2];
-#pragma unroll
-    for (int g = 0; g < SBW / 32; ++g)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        av[g][i] = load_k4(pa[i] + 16 * (g + half * (SBW / 32)), la[i]);
-        bv[g][i] = load_k4(pb[i] + 16 * (g + half * (SBW / 32)), lb[i]);
-      }
-#pragma unroll
-    for (int g = 0; g < SBW / 32; ++g)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][i][u], bv[g][j][u], acc[i][j], 0, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int rr = r0 + 16 * i + lk + 4 * q, cc = c0 + 16 * j + li;
-        if (rr <= D && cc < D && (cc <= rr)) M[(size_t)rr * ld + cc] -= acc[i][j][q];
-      }
-}
-
-// The same update for SMALL trailing matrices (fewer 64 x 64 tiles than CUs): one workgroup per 32 x 32
-// tile, the K = 128 columns split over its four waves (32 each) and the four partial tiles summed
-// through LDS.  A workgroup then loads 72 KiB instead of 160 KiB -- one CU draws only ~25 GB/s from
-// beyond its L2, which is what a 64 x 64 tile's 20 us were -- and four times as many CUs take part.
+// >= jE (jE - jS == SBW).  One workgroup per 32 x 32 tile of the lower triangle, the K = 128 columns
+// split over its four waves (32 each) and the four partial tiles summed through LDS.  Round 1 gave a
+// workgroup a 64 x 64 tile with the whole K per wave: 160 KiB of operands per workgroup instead of
+// 72 KiB, and one CU draws only ~25 GB/s from beyond its L2 -- 20 us per update at D = 893 where
+// this takes 6, and still 0.6 ms slower per solve at D = 4493 (four times fewer workgroups to
+// spread the loads over).
 __global__ __launch_bounds__(256) void k_chol_trail32(double *M, int ld, int D, int jS, int jE) {
   __shared__ double part[4][NB][NB + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -1304,10 +1245,6 @@ __global__ __launch_bounds__(256) void k_chol_trail32(double *M, int ld, int D, 
     const double sum = (part[0][i][j] + part[1][i][j]) + (part[2][i][j] + part[3][i][j]);
     if (rr <= D && cc < D && cc <= rr) M[(size_t)rr * ld + cc] = cv[q] - sum;
   }
-}
-
-__global__ __launch_bounds__(256) void k_chol_trail(double *M, int ld, int D, int jS, int jE) {
-  chol_trail_body(M, ld, D, jS, jE, blockIdx.x, blockIdx.y, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // L^T x = y (y = row D of M, overwritten by x), one launch per 128-column super-block, last one
@@ -2506,17 +2443,16 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
                          h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
-        const int nt = (D + 1 - jE + 63) / 64, nt32 = (D + 1 - jE + NB - 1) / NB;
-        static const int small_max = getenv("MVBA_TRAIL32_MAX") ? atoi(getenv("MVBA_TRAIL32_MAX")) : 2 * h->n_cu;
-        if (nt * (nt + 1) / 2 <= small_max)
-          hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
-        else
-          hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
+        const int nt32 = (D + 1 - jE + NB - 1) / NB;
+        hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
     const int S = (D + SBW - 1) / SBW;
     if (h->chol_onepass && (S == 1 || S < h->n_cu)) {  // one persistent pass for L^T x = y (see k_chol_backsolve_all)
-      const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(h->n_cu - S, ngrp)) : 0;
+      // few bulk workgroups (each then takes several column groups per step): a barrier gets dearer with
+      // every workgroup -- its release/acquire writes back and invalidates that XCD's L2 for everybody on
+      // it.  D = 4493: 16 bulk workgroups 2.75 ms per solve, 64: 2.93, 220: 3.24 (tools/ab_solve.py).
+      const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(std::min(h->n_cu - S, 16), ngrp)) : 0;
       hipLaunchKernelGGL(k_chol_backsolve_all, dim3(S + nbulk), dim3(SUPER_THREADS), BACKSOLVE_LDS, h->stream, h->d_Ared, ld, D, m,
                          h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar);
     } else

@@ -378,10 +378,9 @@ def test_config4_shape_500_cameras_8_virtual_shards():
 
 @pytest.mark.parametrize("n,m,p", [(600, 9, 0.6), (3000, 50, 0.3), (900, 300, 0.06)])
 def test_dense_solve_variants_agree(n, m, p, monkeypatch):
-    """The dense solve has two back-substitutions (one persistent launch with device-wide barriers, or
-    one launch per super-block behind MVBA_CHOL=launches) and two trailing-update kernels (32 x 32 tiles
-    while the trailing matrix is small, 64 x 64 above: MVBA_TRAIL32_MAX moves the switch).  All
-    combinations must give the camera step of the oracle's solve (D = 74, 443, 2693)."""
+    """The dense solve has two back-substitutions: one persistent launch with device-wide barriers, or
+    one launch per super-block behind MVBA_CHOL=launches (also the fallback when the persistent grid
+    could not be co-resident).  Both must give the camera step of the oracle's solve (D = 74, 443, 2693)."""
     sc = make_scene(n, m, vis_p=p)
     g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Dense-solve look-ahead A/B at a given camera count: solve ms per try_step and dxi vs NumPy.
-usage: MVBA_SOLVE_LOOKAHEAD=0|1 python tools/ab_solve.py m"""
+"""Dense-solve A/B at a given camera count: solve ms per try_step and dxi vs NumPy.
+usage: [MVBA_CHOL=launches] [MVBA_TRAIL32_MAX=n] python tools/ab_solve.py m"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "3d-reconstruction-from-multi-view-exp_amd"), ROOT]
@@ -21,4 +21,4 @@ err = np.abs(dxi - ref).max() / np.abs(ref).max()
 eng.set_profiling(True); eng.reset_stats()
 for _ in range(10): eng.try_step(1e-4)
 st = eng.stats()
-print(f"lookahead={os.environ.get('MVBA_SOLVE_LOOKAHEAD','auto')} m={m} D={9*m-7} solve {st['solve']['ms']/10:.3f} ms  schur {st['schur']['ms']/10:.3f}  dxi rel err {err:.2e}  lu {st['counts']['lu_fallback']}")
+print(f"{' '.join(k + '=' + v for k, v in os.environ.items() if k.startswith('MVBA_'))} m={m} D={9*m-7} solve {st['solve']['ms']/10:.3f} ms  schur {st['schur']['ms']/10:.3f}  dxi rel err {err:.2e}  lu {st['counts']['lu_fallback']}")
