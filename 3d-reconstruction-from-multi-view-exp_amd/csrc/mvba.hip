@@ -1655,7 +1655,23 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
                  pb8 = pb[8];
     const double Xa0 = X[3 * a], Xa1 = X[3 * a + 1], Xa2 = X[3 * a + 2];
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    for (long long o = o0 + s; o < o1; o += G) {
+    // the camera ids of this lane's first PF observations in ONE batch (unconditional loads on clamped
+    // indices: one memory latency per point instead of one per observation), the rare rest one by one
+    constexpr int PF = 4;
+    int kk[PF];
+    const long long olast = max(o1 - 1, o0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) kk[u] = cam_idx[min(o0 + s + G * u, olast)];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (o0 + s + G * u < o1) {
+        double t0, t1, t2;
+        obs_backsub(Xa0, Xa1, Xa2, s_cam + kk[u] * CAM_LDS, s_dxi + 9 * kk[u], f0, t0, t1, t2);
+        y0 += t0;
+        y1 += t1;
+        y2 += t2;
+      }
+    for (long long o = o0 + s + G * PF; o < o1; o += G) {
       const int k = cam_idx[o];
       double t0, t1, t2;
       obs_backsub(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, s_dxi + 9 * k, f0, t0, t1, t2);
