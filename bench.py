@@ -147,7 +147,41 @@ def cpu_baseline(sc, n_images, iters=3, workers=None, config2=True):
                                              "kind": "oracle/ba_dense.py (dense broadcast algorithm of ref :103-162), BLAS threads as listed"}
         except Exception as exc:  # noqa: BLE001
             out["dense_faithful_config2"] = {"error": repr(exc)}
+    out["config1_default_scene"] = config1_default_scene()
     return out
+
+
+def config1_default_scene():
+    """the reference's default scene (200 points x 10 cameras, the
+    committed fixture tests/golden/euclid_default.npz captured from the reference), full
+    optimize(2.0, 1e-8, max_iter=100) on the dense-faithful NumPy oracle and on the HIP engine; both
+    must land on the reference's 37 outer iterations / 59 solves and RMSE 0.0063291001035384233."""
+    try:
+        from lib.bundle_adjustment import BundleAdjuster
+        from oracle import ba_dense as Dn
+
+        d = np.load(os.path.join(ROOT, "tests", "golden", "euclid_default.npz"), allow_pickle=False)
+        args = (d["x"], d["init_X"], d["init_K"], d["init_R"], d["init_t"])
+        res = {"workload": "200 points x 10 cameras (tests/golden/euclid_default.npz), optimize(2.0, 1e-8, max_iter=100)",
+               "expected": {"outer_iterations": 37, "solves": 59, "rmse": 0.0063291001035384233}}
+        for name, make in (("cpu_dense_faithful", lambda: Dn.DenseBundleAdjuster(*args, axis="x-up_z-forward")),
+                           ("gpu", lambda: BundleAdjuster(*args, axis="x-up_z-forward"))):
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ba = make()
+                    t0 = time.perf_counter()
+                    ba.optimize(2.0, 1e-8, max_iter=100, is_debug=True)
+                    dt = time.perf_counter() - t0
+                log = ba.get_log()
+                eng = getattr(ba, "_engine", None) or ba.engine
+                n_outer = len(log) - 1
+                res[name] = {"seconds": dt, "it_per_s": n_outer / dt, "outer_iterations": n_outer, "solves": int(eng.n_solves),
+                             "rmse": float(np.sqrt(log[-1]["reprojection_error"] / 2000.0))}
+            except Exception as exc:  # noqa: BLE001  (no GPU: the CPU leg still reports)
+                res[name] = {"error": repr(exc)}
+        return res
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
 
 
 def main():

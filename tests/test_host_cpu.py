@@ -139,3 +139,16 @@ def test_bench_cpu_baseline_and_pmc_helpers():
     assert 0.95 < t / (152 * d["n_obs"] + 96 * d["n_points"]) < 1.10  # HBM traffic ~ algorithmic bytes
     assert bench.pmc_traffic("k_resid_jac", d["n_obs"] + 1) == (None, None)
     assert bench.pmc_traffic("no_such_kernel", d["n_obs"]) == (None, None)
+
+
+def test_bench_config1_leg_reproduces_the_reference_counts_on_the_cpu():
+    """bench.py's config-1 leg: the dense-faithful oracle on the reference's default
+    scene lands on 37 outer iterations / 59 solves / RMSE 0.0063291001035384233; without a GPU the
+    HIP leg reports an error instead of taking the CPU leg down with it."""
+    import bench
+
+    r = bench.config1_default_scene()
+    cpu = r["cpu_dense_faithful"]
+    assert (cpu["outer_iterations"], cpu["solves"]) == (37, 59)
+    assert abs(cpu["rmse"] - r["expected"]["rmse"]) < 1e-9
+    assert "gpu" in r and ("error" in r["gpu"] or r["gpu"]["solves"] == 59)
