@@ -573,3 +573,60 @@ def test_config4_per_gpu_shard_full_size_properties():
     _timing_line(f"config-4 per-GPU shard+ ({n} points x {m} cameras x 5 %, {sc.n_obs} obs, {info['items']} pair items, "
                  f"{info['units']} units): {dt / 3 * 1e3:.2f} ms per LM iteration ({solves} solves in 3 iterations); "
                  f"ms per solve: {per}; scene generation {t_gen:.1f} s, engine create {t_create:.1f} s")
+
+
+def test_config4_in_full_on_one_gpu():
+    """BASELINE config 4 ITSELF -- 10M points x 500 cameras x 5 % = 250M observations, 3.4G pair items --
+    on ONE GPU (it fits: ~85 GB of the 288).  Size-independent properties: the device cost equals an
+    independent NumPy cost (streamed over the observations in chunks), the cost falls monotonically
+    over two LM iterations to the noise floor, the gauge camera is untouched, no LU rescue."""
+    import time
+
+    m, n = 500, 10_000_000
+    t0 = time.perf_counter()
+    sc = make_scene(n, m, vis_p=0.05)
+    t_gen = time.perf_counter() - t0
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    f, u = sc.init_K[:, 0, 0], sc.init_K[:, :2, 2]
+    t0 = time.perf_counter()
+    full = _mvba.HipEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    t_create = time.perf_counter() - t0
+    full.set_params(X, f, u, t, R)
+    E0 = full.cost()
+    E0_np, step = 0.0, 500_000  # points per chunk (~12.5M observations)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        o0, o1 = int(sc.pt_ptr[lo]), int(sc.pt_ptr[hi])
+        pt = np.repeat(np.arange(lo, hi), np.diff(sc.pt_ptr[lo:hi + 1]))
+        E0_np += O.cost(X, f, u, t, R, 1.0, pt, sc.cam_idx[o0:o1], sc.xy[o0:o1])
+    assert E0 == pytest.approx(E0_np, rel=1e-10)
+    costs, c = [E0], 1e-4
+    full.set_profiling(True)
+    full.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        full.linearize()
+        while True:
+            E_ = full.try_step(c)
+            if E_ > costs[-1]:
+                c *= 2.0
+            else:
+                break
+        full.commit()
+        costs.append(E_)
+        c /= 2.0
+    dt = time.perf_counter() - t0
+    st = full.stats()
+    assert all(b2 < a2 for a2, b2 in zip(costs, costs[1:]))
+    assert np.sqrt(costs[-1] / sc.n_obs) < 1.4e-3
+    Xn, fn, un, tn, Rn = full.get_params()
+    np.testing.assert_array_equal(tn[0], t[0])
+    np.testing.assert_array_equal(Rn[0], R[0])
+    assert st["counts"]["lu_fallback"] == 0
+    solves = max(st["counts"]["try_step"], 1)
+    per = ", ".join(f"{k} {v['ms'] / solves:.3f}" for k, v in st.items() if k != "counts" and v["launches"])
+    info = full.schur_info()
+    _timing_line(f"config 4 in full on one GPU ({n} points x {m} cameras x 5 %, {sc.n_obs} obs, {info['items']} pair items, "
+                 f"{info['units']} units): {dt / 2 * 1e3:.2f} ms per LM iteration ({solves} solves in 2 iterations); "
+                 f"ms per solve: {per}; scene generation {t_gen:.1f} s, engine create {t_create:.1f} s")
+    full.close()
