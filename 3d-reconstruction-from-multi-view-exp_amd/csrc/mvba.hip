@@ -5,7 +5,8 @@
 //   K1  k_resid_jac      residual + 2x3 / 2x9 Jacobian rows per observation   (ref :291-427)
 //   K2  (fused into K1)  E_a = 2 sum JxT Jx, dP_a = 2 sum JxT e               (ref :429-469, :519-556)
 //   K3a k_point_inv      damped 3x3 inverse, v_a = E^-1 dP_a                  (ref :120-128)
-//   K3  k_schur_strip    A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
+//   K3  k_schur_pairs + k_schur_reduce (k_schur_strip behind MVBA_SCHUR=strip)
+//                        A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
 //   C1  ncclAllReduce    [A|b] across point shards                            
 //   K4  k_chol_super / k_chol_trail32 / k_chol_backsolve_all (+ k_lu_solve rescue)
 //                        dense solve of the gauge-reduced system              (ref :146)
@@ -16,8 +17,8 @@
 //   slot 4-6  dJ/domega columns    slot 7    residual e
 // J_C's translation columns are exactly -J_X and its (u,v) columns are the
 // constants (1/f0,0),(0,1/f0) (ref :350-376), so the 2x9 block is implied by the
-// record.  A point's observations are consecutive lines, which is what makes the
-// camera-major Schur gather cheap (one line per (point,camera) pair).
+// record.  A point's observations are consecutive lines; the Schur kernel gathers whole lines
+// (k-side record, l-side record, point block) per (point, camera pair) item.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
