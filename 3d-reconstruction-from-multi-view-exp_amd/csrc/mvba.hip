@@ -523,7 +523,7 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_unifo
 // per load, and so does a spilled register reloaded between two DMAs -- either drains the DMAs in
 // flight.  Only lane 63 of a record DMA is masked off (9 rows x 7 slots = 63 lanes; its 16 bytes
 // would land on the next chunk's first slot).
-template <bool DIAG>
+template <bool DIAG, bool BIG>
 __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, const long long beg, const int n,
                                                  const int *__restrict__ it_k, const int *__restrict__ it_l,
                                                  const int *__restrict__ it_a, const double2 *__restrict__ rec,
@@ -547,36 +547,64 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 
   int ixk[3], ixl[3], ixa[2];
   auto load_idx = [&](int s0) {  // indices of the step starting at item s0 (to registers)
-    const int last = min(PSTEP, n - s0) - 1;
-    const int *pk = it_k + beg + s0, *pl = it_l + beg + s0, *pa = it_a + beg + s0;
+    // uniform base + unsigned 32-bit row: the saddr form again (written with int rows the clamps and the
+    // address sums were done in 64 bits per lane: ~40 vector instructions per step for seven loads)
+    // (the bases go through readfirstlane and the rows through an empty asm so that the compiler can neither
+    // split the uniform sum into per-lane 64-bit additions nor widen the clamp to 64 bits)
+    const unsigned last = (unsigned)(min(PSTEP, n - s0) - 1);
+    typedef const int __attribute__((address_space(1))) *gint_p;  // (a plain pointer rebuilt from integers would be a FLAT one)
+    auto uni = [](const int *p) {
+      const unsigned long long v = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return (gint_p)(((unsigned long long)hi << 32) | lo);
+    };
+    typedef const char __attribute__((address_space(1))) *gchar_p;
+    auto row_of = [&](int r) {  // BYTE offset of the clamped row
+      unsigned off = min((unsigned)r, last) << 2;
+      asm("" : "+v"(off));
+      return off;
+    };
+    auto at = [](gint_p base, unsigned off) { return *(gint_p)((gchar_p)base + off); };
+    const gint_p pk = uni(it_k + (beg + s0)), pl = DIAG ? pk : uni(it_l + (beg + s0)), pa = uni(it_a + (beg + s0));
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const int row = min(9 * q + drow, last);
-      ixk[q] = pk[row];
-      if (!DIAG) ixl[q] = pl[row];
+      const unsigned row = row_of(9 * q + drow);
+      ixk[q] = at(pk, row);
+      if (!DIAG) ixl[q] = at(pl, row);
     }
-    if (DIAG) ixl[0] = pk[min(lane, last)];  // the record whose residual slot this lane fetches
-    ixa[0] = pa[min(prow, last)];
-    if (DIAG) ixa[1] = pa[min(prow2, last)];
+    if (DIAG) ixl[0] = at(pk, row_of(lane));  // the record whose residual slot this lane fetches
+    ixa[0] = at(pa, row_of(prow));
+    if (DIAG) ixa[1] = at(pa, row_of(prow2));
+  };
+  // Addresses as "uniform base + 32-bit byte offset" (the saddr form of the memory instructions: one
+  // shift-add per address instead of a sign extension, a 64-bit shift and a 64-bit add); BIG: the
+  // records or the point blocks span 4 GiB or more and the offsets need 64 bits.
+  auto rec_at = [&](int obs, int slot) -> const void * {
+    if (BIG) return rec + (size_t)obs * REC + slot;
+    return reinterpret_cast<const char *>(rec) + (((unsigned)obs << 7) + ((unsigned)slot << 4));
+  };
+  auto pb_at = [&](int a, int slot) -> const void * {
+    if (BIG) return PB + (size_t)a * PBS + 2 * slot;
+    return reinterpret_cast<const char *>(PB) + (((unsigned)a << 7) + ((unsigned)slot << 4));
   };
   auto issue = [&](char *buf) {
     char *kb = buf, *lb = buf + PSTEP * PROW, *pb_ = lb + PSTEP * PROW;
     if (lane < 63) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        lds_dma16(rec + (size_t)ixk[q] * REC + dslot, kb + q * (9 * PROW));
-        if (!DIAG) lds_dma16(rec + (size_t)ixl[q] * REC + dslot, lb + q * (9 * PROW));
+        lds_dma16(rec_at(ixk[q], dslot), kb + q * (9 * PROW));
+        if (!DIAG) lds_dma16(rec_at(ixl[q], dslot), lb + q * (9 * PROW));
       }
-      if (!DIAG) lds_dma16(PB + (size_t)ixa[0] * PBS + 2 * pslot, pb_);
+      if (!DIAG) lds_dma16(pb_at(ixa[0], pslot), pb_);
     }
     if (lane < 7 * (PSTEP - 18)) {  // third chunk: rows 18..20 only (a buffer holds 21 rows)
-      lds_dma16(rec + (size_t)ixk[2] * REC + dslot, kb + 2 * (9 * PROW));
-      if (!DIAG) lds_dma16(rec + (size_t)ixl[2] * REC + dslot, lb + 2 * (9 * PROW));
+      lds_dma16(rec_at(ixk[2], dslot), kb + 2 * (9 * PROW));
+      if (!DIAG) lds_dma16(rec_at(ixl[2], dslot), lb + 2 * (9 * PROW));
     }
     if (DIAG) {  // l-side == k-side: only the residual (slot 7) is fetched, 16 bytes per item
-      if (lane < PSTEP) lds_dma16(rec + (size_t)ixl[0] * REC + 7, lb);
-      lds_dma16(PB + (size_t)ixa[0] * PBS + 2 * pslot, pb_);
-      if (lane < 5 * PSTEP - 64) lds_dma16(PB + (size_t)ixa[1] * PBS + 2 * pslot2, pb_ + 1024);
+      if (lane < PSTEP) lds_dma16(rec_at(ixl[0], 7), lb);
+      lds_dma16(pb_at(ixa[0], pslot), pb_);
+      if (lane < 5 * PSTEP - 64) lds_dma16(pb_at(ixa[1], pslot2), pb_ + 1024);
     }
   };
   load_idx(0);
@@ -672,6 +700,7 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 
 // One wave per block: a wave works alone, and in a wider block its LDS and wave slots stay taken until
 // the block's slowest wave has finished (4 waves per block: 1.945 ms, 2: 1.92, 1: 1.89 at config 3).
+template <bool BIG>
 __global__ __launch_bounds__(64, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
                                                        const int *__restrict__ q_units, int *__restrict__ head,
                                                        const int *__restrict__ it_k, const int *__restrict__ it_l,
@@ -702,13 +731,17 @@ __global__ __launch_bounds__(64, 3) void k_schur_pairs(const int4 *__restrict__ 
   }
   pos = __builtin_amdgcn_readfirstlane(pos);
   if (pos < 0) return;
-  const int u = q_units[pos];   // unit id (where its partial goes) and descriptor, both in queue order:
-  const int4 ud = units[pos];   // two independent loads instead of a dependent pair
-  const long long beg = ((long long)ud.y << 32) | (unsigned)ud.x;
-  const int n = ud.z, cam_k = (int)((unsigned)ud.w >> 16), cam_l = ud.w & 0xffff;
+  // unit id (where its partial goes) and descriptor, both in queue order: two independent SCALAR loads
+  // (pos is wave-uniform; read through the constant address space so that beg and n live in SGPRs and
+  // the per-step index bases are scalar arithmetic)
+  const int u = as_const(q_units)[pos];
+  const int MVBA_CONST_AS *udp = as_const(reinterpret_cast<const int *>(units)) + 4 * (size_t)pos;
+  const int ud_x = udp[0], ud_y = udp[1], ud_z = udp[2], ud_w = udp[3];
+  const long long beg = ((long long)ud_y << 32) | (unsigned)ud_x;
+  const int n = ud_z, cam_k = (int)((unsigned)ud_w >> 16), cam_l = ud_w & 0xffff;
   double *out = partial + (size_t)u * UNIT_STRIDE;
-  if (cam_k == cam_l) schur_pairs_unit<true>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
-  else schur_pairs_unit<false>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+  if (cam_k == cam_l) schur_pairs_unit<true, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+  else schur_pairs_unit<false, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
 }
 
 // One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
@@ -2423,9 +2456,11 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_SCHUR);
     if (h->n_units) {
       static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));  // experiment knob
-      hipLaunchKernelGGL(k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64), 2 * PWAVE_LDS, h->stream, h->d_units,
-                         h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c,
-                         h->f0, h->d_partial);
+      // 64-bit offsets only when the records or the point blocks span 4 GiB (MVBA_FORCE_BIG: at test sizes too)
+      const bool big = std::max<long long>(h->nobs, h->N) * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");
+      hipLaunchKernelGGL(big ? k_schur_pairs<true> : k_schur_pairs<false>, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
+                         2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k,
+                         h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
     }
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,
                        h->d_partial, d_A, d_b, h->d_q_head);
