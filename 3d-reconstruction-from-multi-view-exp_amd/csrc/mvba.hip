@@ -701,7 +701,7 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 // One wave per block: a wave works alone, and in a wider block its LDS and wave slots stay taken until
 // the block's slowest wave has finished (4 waves per block: 1.945 ms, 2: 1.92, 1: 1.89 at config 3).
 template <bool BIG>
-__global__ __launch_bounds__(64, 3) void k_schur_pairs(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
+__device__ __forceinline__ void schur_pairs_wave(const int4 *__restrict__ units, const int *__restrict__ q_ptr,
                                                        const int *__restrict__ q_units, int *__restrict__ head,
                                                        const int *__restrict__ it_k, const int *__restrict__ it_l,
                                                        const int *__restrict__ it_a, const double2 *__restrict__ rec,
@@ -742,6 +742,18 @@ __global__ __launch_bounds__(64, 3) void k_schur_pairs(const int4 *__restrict__ 
   double *out = partial + (size_t)u * UNIT_STRIDE;
   if (cam_k == cam_l) schur_pairs_unit<true, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
   else schur_pairs_unit<false, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+}
+
+#define MVBA_PAIRS_ARGS                                                                                                   \
+  const int4 *__restrict__ units, const int *__restrict__ q_ptr, const int *__restrict__ q_units, int *__restrict__ head, \
+      const int *__restrict__ it_k, const int *__restrict__ it_l, const int *__restrict__ it_a,                          \
+      const double2 *__restrict__ rec, const double *__restrict__ PB, double c, double f0, double *__restrict__ partial
+// (two plain kernels rather than one template, so that profiles show one stable name per variant)
+__global__ __launch_bounds__(64, 3) void k_schur_pairs(MVBA_PAIRS_ARGS) {
+  schur_pairs_wave<false>(units, q_ptr, q_units, head, it_k, it_l, it_a, rec, PB, c, f0, partial);
+}
+__global__ __launch_bounds__(64, 3) void k_schur_pairs_big(MVBA_PAIRS_ARGS) {  // 64-bit record / point-block offsets
+  schur_pairs_wave<true>(units, q_ptr, q_units, head, it_k, it_l, it_a, rec, PB, c, f0, partial);
 }
 
 // One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
@@ -2458,7 +2470,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));  // experiment knob
       // 64-bit offsets only when the records or the point blocks span 4 GiB (MVBA_FORCE_BIG: at test sizes too)
       const bool big = std::max<long long>(h->nobs, h->N) * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");
-      hipLaunchKernelGGL(big ? k_schur_pairs<true> : k_schur_pairs<false>, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
+      hipLaunchKernelGGL(big ? k_schur_pairs_big : k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
                          2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k,
                          h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
     }
