@@ -913,7 +913,7 @@ __device__ __forceinline__ bool factor_tile(const double (*tile)[TS], double (*Z
     for (int j = 0; j < 8; ++j) bp[j] = Xb[lane * XBS + j];
     FT_STAMP(1 + 4 * p);
     // b. elimination inside the panel
-#ifdef MVBA_FACTOR_PAIRS
+#ifndef MVBA_FACTOR_SINGLE  // (define it for the one-pivot-per-step elimination: tools/microbench/factor_tile_test.hip times both)
     // Two pivots per step: with a = B[k][k], b = B[k+1][k], c = B[k+1][k+1] the two reciprocal roots
     // 1/l11 = rsq(a) and 1/l22 = rsq(a c - b^2) * l11 do not depend on each other, so the serial chain
     // (rsq + two Newton steps + broadcast) is walked 16 times per tile instead of 32.  a c - b^2
