@@ -257,25 +257,44 @@ constexpr int PBS = 16;
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
                                                    double *__restrict__ PB, int *__restrict__ flag,
                                                    double *__restrict__ Ab, long long nAb) {
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // a block's 256 points are 18 KiB of PL and 32 KiB of PB, both contiguous: moved with coalesced
+  // accesses through LDS (a thread reading its own 72-byte row / writing its own 128-byte line touches
+  // 64 different lines per instruction)
+  __shared__ double s_in[256 * 9 + 8];
+  __shared__ double2 s_out[256 * 8];
+  const long long a0 = (long long)blockIdx.x * 256, a = a0 + threadIdx.x;
   for (long long i = a; i < nAb; i += (long long)gridDim.x * blockDim.x) Ab[i] = 0.0;
-  if (a >= npts) return;
-  const double *in = PL + 9 * a;
-  const double s = 1.0 + c;
-  const double xx = in[0] * s, xy = in[1], xz = in[2], yy = in[3] * s, yz = in[4], zz = in[5] * s;
-  const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
-  const double det = xx * c00 + xy * c01 + xz * c02;
-  if (!(det != 0.0) || !isfinite(det)) atomicOr(flag, 1);  // singular 3x3 (ref :128 raises LinAlgError)
-  const double id = 1.0 / det;
-  const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-  const double i11 = (xx * zz - xz * xz) * id, i12 = (xy * xz - xx * yz) * id, i22 = (xx * yy - xy * xy) * id;
-  double *out = PB + PBS * a;
-  out[0] = i00; out[1] = i01; out[2] = i02; out[3] = i11; out[4] = i12; out[5] = i22;
-  const double g0 = in[6], g1 = in[7], g2 = in[8];
-  out[6] = i00 * g0 + i01 * g1 + i02 * g2;
-  out[7] = i01 * g0 + i11 * g1 + i12 * g2;
-  out[8] = i02 * g0 + i12 * g1 + i22 * g2;
-  out[9] = 0.0;
+  if (a0 >= npts) return;  // (uniform)
+  const int np = (int)min<long long>(256, npts - a0);
+  for (int e = threadIdx.x; e < 9 * np; e += 256) s_in[e] = PL[9 * a0 + e];
+  __syncthreads();
+  if (threadIdx.x < np) {
+    const double *in = s_in + 9 * threadIdx.x;
+    const double s = 1.0 + c;
+    const double xx = in[0] * s, xy = in[1], xz = in[2], yy = in[3] * s, yz = in[4], zz = in[5] * s;
+    const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
+    const double det = xx * c00 + xy * c01 + xz * c02;
+    if (!(det != 0.0) || !isfinite(det)) atomicOr(flag, 1);  // singular 3x3 (ref :128 raises LinAlgError)
+    const double id = 1.0 / det;
+    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+    const double i11 = (xx * zz - xz * xz) * id, i12 = (xy * xz - xx * yz) * id, i22 = (xx * yy - xy * xy) * id;
+    const double g0 = in[6], g1 = in[7], g2 = in[8];
+    // slot s of point p sits at s_out[8 p + (s ^ (p & 7))]: conflict-free 16-byte LDS stores, undone on the way out
+    double2 *out = s_out + 8 * threadIdx.x;
+    const int sw = threadIdx.x & 7;
+    out[0 ^ sw] = make_double2(i00, i01);
+    out[1 ^ sw] = make_double2(i02, i11);
+    out[2 ^ sw] = make_double2(i12, i22);
+    out[3 ^ sw] = make_double2(i00 * g0 + i01 * g1 + i02 * g2, i01 * g0 + i11 * g1 + i12 * g2);
+    out[4 ^ sw] = make_double2(i02 * g0 + i12 * g1 + i22 * g2, 0.0);
+    out[5 ^ sw] = out[6 ^ sw] = out[7 ^ sw] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  double2 *dst = reinterpret_cast<double2 *>(PB + PBS * a0);
+  for (int e = threadIdx.x; e < 8 * np; e += 256) {
+    const int p = e >> 3, sl = e & 7;
+    dst[e] = s_out[8 * p + (sl ^ (p & 7))];
+  }
 }
 
 // ------------------------------------------------------------------ K3
