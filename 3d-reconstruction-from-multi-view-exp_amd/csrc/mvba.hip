@@ -1771,10 +1771,21 @@ __global__ __launch_bounds__(256) void k_cost(long long nobs, int m, const doubl
   __syncthreads();
   double cost = 0.0;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < nobs; o += stride) {
-    const double *Xa = X + 3 * (size_t)obs_pt[o];
-    const double2 z = xy[o];
-    cost += obs_cost(Xa[0], Xa[1], Xa[2], s_cam + cam_idx[o] * CAM_LDS, z.x, z.y, f0);
+  // two dependent memory latencies per observation (its indices, then its point): the next
+  // observation's indices are requested before this one is evaluated (clamped, unconditional loads)
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long olast = nobs - 1;
+  int a_n = obs_pt[min(o, olast)], k_n = cam_idx[min(o, olast)];
+  double2 z_n = xy[min(o, olast)];
+  for (; o < nobs; o += stride) {
+    const int a = a_n, k = k_n;
+    const double2 z = z_n;
+    const double X0 = X[3 * (size_t)a], X1 = X[3 * (size_t)a + 1], X2 = X[3 * (size_t)a + 2];
+    const long long on = min(o + stride, olast);
+    a_n = obs_pt[on];
+    k_n = cam_idx[on];
+    z_n = xy[on];
+    cost += obs_cost(X0, X1, X2, s_cam + k * CAM_LDS, z.x, z.y, f0);
   }
   const double t = block_sum(cost, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
