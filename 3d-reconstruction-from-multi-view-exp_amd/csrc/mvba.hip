@@ -2196,7 +2196,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     // a pair much larger than the typical off-diagonal one (the diagonal pairs: every observation of
     // the camera) is dealt round-robin into S sub-lists that sweep the points at the common pace
     const long long target = std::max<long long>(1, (T - Tdiag) / std::max<long long>(1, P - m));
-    long long unit_items = 768;  // items per unit (a wave's run): shorter units keep the sibling units of a strip closer together in time (L2 hits on the k side: 32 % at 1536, 44 % at 768), below ~500 the per-unit prologue costs more than that buys
+    // items per unit (a wave's run): shorter units keep the sibling units of a strip closer together in time (more L2
+    // hits on the k side) but cost a serial prologue and a 27-value tree each.  With one-wave blocks and static
+    // assignment the best length is ~600 (config 3: 1.99 / 1.86 / 1.80 / 1.81 / 1.89 / 2.03 ms at 320 / 448 / 576 /
+    // 640 / 768 / 1024; with four-wave blocks and atomic queues it was 768)
+    long long unit_items = 600;
     if (const char *ev = getenv("MVBA_PAIR_UNIT")) unit_items = std::max(21, atoi(ev));
     std::vector<int> S(P), vp_ptr(P + 1, 0);
     for (long long q = 0; q < P; ++q) {
