@@ -1697,6 +1697,7 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 // and it is evaluated as a directional derivative (obs_backsub: ~75 fp64 operations, the Jacobian rows
 // are never formed) -- the same linear map the Schur kernel assembled, implied columns included.
 // The trial cost is k_cost on the trial state (K6).
+template <int G>
 __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
                                                  const int *__restrict__ cam_idx, const double *__restrict__ PB,
                                                  const double *__restrict__ dxi, const double *__restrict__ X,
@@ -1707,7 +1708,8 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
   for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
-  constexpr int G = 4;  // lanes per point
+  // G lanes per point (template).  Measured with 2 / 4 / 8 lanes: config 3 (10 observations per point)
+  // 0.198 / 0.207 / 0.235 ms, config-4 shard (25 per point) 0.783 / 0.816 / 0.873 ms; one lane: 0.208
   const int s = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   const long long a_first = (long long)blockIdx.x * (256 / G) + grp, a_step = (long long)gridDim.x * (256 / G);
   long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
@@ -2360,7 +2362,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
-  TRYH(hipFuncSetAttribute((const void *)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_backsub<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute((const void *)k_backsub<8>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
   TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
   {
@@ -2567,10 +2571,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_BACKSUB_COST);
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
-    const int nblk = (int)std::min<long long>(4096, (h->N + 63) / 64);
-    if (nblk) {
+    if (h->N) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
-      hipLaunchKernelGGL(k_backsub, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
+      static const int lanes_env = getenv("MVBA_BACKSUB_LANES") ? atoi(getenv("MVBA_BACKSUB_LANES")) : 0;  // experiment knob
+      const double deg = (double)h->nobs / (double)h->N;
+      const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
+      const int nblk = (int)std::min<long long>(4096, (h->N * G + 255) / 256);
+      auto kern = G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>);
+      hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
                          h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX);
     }
     // K6: trial cost = the residual-only pass at the trial state (fixed grid, fixed tree: deterministic)
