@@ -520,15 +520,17 @@ void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) {
   hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dG, n);
 }
 
-void launch_jacobi(mvsvd_handle *h, double *dVout) {
+// tol: rotate while |a_pq| > tol sqrt(|a_pp a_qq|).  1e-15 for float64 input; float32 input carries
+// 6e-8 of relative noise per entry, so its Gram matrix is diagonalised to 1e-11 (one or two sweeps fewer).
+void launch_jacobi(mvsvd_handle *h, double *dVout, double tol) {
   const int n = h->n, np = (n + 1) & ~1;
   const size_t nn = (size_t)n * n, jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
   if (n <= JW)
-    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
+    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, h->st, h->dG, dVout, n, 60, tol, h->dsw);
   else if (n <= 64)
-    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, h->dG, dVout, n, 60, tol, h->dsw);
   else
-    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, h->st, h->dG, dVout, n, 60, 1e-15, h->dsw);
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, h->st, h->dG, dVout, n, 60, tol, h->dsw);
 }
 
 int chunks_for(long long n_rows, int n) {
@@ -557,13 +559,13 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
   }
   launch_gram<T>(h, dW, mu, chunks);
   hipEventRecord(h->ev[2], st);
-  launch_jacobi(h, refine ? h->dV1 : h->dV);
+  launch_jacobi(h, refine ? h->dV1 : h->dV, sizeof(T) == 8 ? 1e-15 : 1e-11);
   hipEventRecord(h->ev[3], st);
   if (refine) {
     if (!h->dB) MVBA_HIP(hipMalloc((void **)&h->dB, sizeof(double) * (size_t)h->max_rows * n));
     hipLaunchKernelGGL(k_rotate<T>, dim3((unsigned)((n_rows + 63) / 64), (n + 63) / 64), dim3(256), 0, st, dW, n_rows, n, mu, h->dV1, h->dB);
     launch_gram<double>(h, h->dB, nullptr, chunks);
-    launch_jacobi(h, h->dMr /* V2, n x n: dMr is sized for it */);
+    launch_jacobi(h, h->dMr /* V2, n x n: dMr is sized for it */, 1e-15);
     // V = V1 V2
     hipLaunchKernelGGL(k_rotate<double>, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, st, h->dV1, (long long)n, n, (const double *)nullptr,
                        h->dMr, h->dV);
