@@ -201,6 +201,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
     args = ap.parse_args()
+    # Rank 0's stdout must carry ONE JSON line and nothing else, but libraries write there too (RCCL
+    # prints a five-line version banner at communicator creation): everything this process and its
+    # libraries print goes to stderr, the JSON line alone to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -386,7 +392,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, n_cams, iters=args.cpu_iters, workers=args.cpu_workers)
             if args.svd_rows > 0:
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
