@@ -284,7 +284,7 @@ def test_virtual_point_shards_sum_to_the_full_reduced_system():
     assert withc.cost() == pytest.approx(full.cost(), rel=1e-13)
 
 
-@pytest.mark.parametrize("n,m,p", [(40, 2, 1.0), (900, 300, 0.06)])
+@pytest.mark.parametrize("n,m,p", [(40, 2, 1.0), (900, 300, 0.06), (3000, 646, 0.04)])  # 646 = the largest count the LDS camera tables allow
 def test_extreme_camera_counts_vs_oracle(n, m, p):
     """m = 2 (smallest legal gauge: D = 11) and m = 300 (the LDS strip of one camera no longer
     fits and is cut into column segments, the path BASELINE config 4 with m = 500 takes)."""
