@@ -11,11 +11,18 @@ trial cost, commit; the LM control flow is the reference's own
 
 N = 1   BASELINE config 3: 1M points x 100 cameras, 10 % visibility (the configuration the
         metric is quoted on).
-N > 1   (one process per GPU, launched by torch.distributed.run)  BASELINE config 4:
-        10M points x 500 cameras, 5 % visibility, STRONG scaling -- the fixed global scene is
-        split by point id into N observation-balanced shards, one RCCL all-reduce of the
-        packed reduced camera system per LM solve.  `value` = plain it/s of the whole job.
-        `--weak` instead gives every rank a config-3-sized shard (round-1 behaviour).
+N > 1   (one process per GPU)  BASELINE config 4: 10M points x 500 cameras, 5 % visibility,
+        STRONG scaling -- the fixed global scene is split by point id into N observation-balanced
+        shards, one RCCL all-reduce of the packed reduced camera system per LM solve.
+        `value` = plain it/s of the whole job.  `--weak` instead gives every rank a
+        config-3-sized shard (round-1 behaviour).
+        Started either by a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py
+        --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or
+        plainly as `python bench.py --gpus N ...`: with no WORLD_SIZE in the environment the
+        process starts that launcher itself as a CHILD (before anything touches the GPU), forwards
+        rank 0's JSON line and exits with the child's status.
+        `--transport host` moves the all-reduce through the host (gloo) and lets the ranks share
+        GPUs (rank r on device r mod device count): the whole N > 1 bench path on a one-GPU box.
 
 Prints ONE JSON line on rank 0.
 """
@@ -184,6 +191,46 @@ def config1_default_scene():
         return {"error": repr(exc)}
 
 
+def launcher_command(argv, n_gpus, port):
+    """The command `python bench.py --gpus N ...` starts when no launcher started IT: one process
+    per GPU under torch.distributed.run, same arguments (the driver's contract form)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, n_gpus):
+    """Run the N-rank job as a child process and forward its one JSON line.  Called before torch is
+    imported: this process never initialises the GPU (a process that has must not exec another)."""
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(argv, n_gpus, free_port())
+    print("bench.py: no WORLD_SIZE in the environment, starting", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+        except ValueError:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,7 +247,12 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
+                    help="N>1: rccl = one GPU per rank, ncclAllReduce inside libmvba (default); host = the reduced system is "
+                         "staged through the host and summed over gloo, ranks may share a GPU (one-GPU rehearsal of the N>1 path)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     # Rank 0's stdout must carry ONE JSON line and nothing else, but libraries write there too (RCCL
     # prints a five-line version banner at communicator creation): everything this process and its
     # libraries print goes to stderr, the JSON line alone to the real stdout at the end.
@@ -216,7 +268,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    host_transport = args.transport == "host"
+    device = local_rank % max(torch.cuda.device_count(), 1) if host_transport else local_rank
+    torch.cuda.set_device(device)
     # MVBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, communicator inside
     # libmvba, all-reduce per solve) even at world size 1 -- the rehearsal a one-GPU box allows.
     multi = world > 1 or os.environ.get("MVBA_BENCH_FORCE_DIST") == "1"
@@ -225,7 +279,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    cdev = "cpu" if host_transport else "cuda"  # where the bench's own scalars are reduced
 
     from lib import _distributed, _mvba
     from lib.bundle_adjustment import BundleAdjuster, LevenbergMarquardt
@@ -247,11 +305,11 @@ def main():
     t_gen = time.perf_counter() - t_gen
     t_create = time.perf_counter()
     ba = BundleAdjuster.from_observations(sc.n_points, n_cams, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
-                                          sc.init_R, sc.init_t, axis=sc.axis, device=local_rank)
+                                          sc.init_R, sc.init_t, axis=sc.axis, device=device)
     t_create = time.perf_counter() - t_create
     eng = ba._engine
     if multi:
-        _distributed.attach_rccl(eng)
+        (_distributed.attach_host_comm if host_transport else _distributed.attach_rccl)(eng)
 
     def fence():
         if multi:
@@ -309,10 +367,10 @@ def main():
     t_api = time.perf_counter() - ta
 
     if multi:
-        tt = torch.tensor([dt, t_api], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, t_api], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, t_api = float(tt[0].item()), float(tt[1].item())
-        no = torch.tensor([sc.n_obs], dtype=torch.float64, device="cuda")
+        no = torch.tensor([sc.n_obs], dtype=torch.float64, device=cdev)
         dist.all_reduce(no)
         n_obs_total = int(no.item())
     else:
@@ -371,8 +429,17 @@ def main():
                                     + (" x point shards (weak scaling: every rank holds a config-3 shard)" if scaling == "weak" and world > 1 else ""),
                 "episode_iterations": EPISODE, "episode_restarts_in_timed_region": n_restarts - restarts0,
                 "scene_generation_s": t_gen, "engine_create_s": t_create,
-                "rccl": eng.rccl_version() if multi else None,
+                "parallelism": f"point shards x{world}" + ("" if not multi else (", host-staged all-reduce over gloo" if host_transport
+                                                                                 else ", RCCL all-reduce")),
+                "transport": (args.transport if multi else None),
+                "rccl": (eng.rccl_version() if multi and not host_transport else
+                         ({"loaded": None, "compiled_against": None, "ranks": world} if multi else None)),
+                "ranks_per_device": (world / max(torch.cuda.device_count(), 1) if host_transport and multi else 1),
             },
+            # C1: one all-reduce of the packed [A|b] per inner solve (+ the 16-byte cost/status all-gather)
+            "allreduce": ({"ms_per_solve": st["allreduce"]["ms"] / max(n_solves, 1),
+                           "bytes_per_solve": 8 * (81 * n_cams * (n_cams + 1) // 2 + 9 * n_cams), "ranks": world,
+                           "transport": args.transport} if multi else None),
             "resid_jac_gobs_per_s": n_obs_total / (k1_ms * 1e-3) / 1e9,
             "inner_solves": n_solves,
             "ms_per_inner_solve": ms_solve,

@@ -6,6 +6,7 @@ without a GPU."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -152,3 +153,36 @@ def test_bench_config1_leg_reproduces_the_reference_counts_on_the_cpu():
     assert (cpu["outer_iterations"], cpu["solves"]) == (37, 59)
     assert abs(cpu["rmse"] - r["expected"]["rmse"]) < 1e-9
     assert "gpu" in r and ("error" in r["gpu"] or r["gpu"]["solves"] == 59)
+
+
+def test_bench_self_launch_command_and_forwarding(monkeypatch, capsys):
+    """`python bench.py --gpus N ...` without a launcher starts torch.distributed.run itself as a
+    child (the driver's contract form) with the same arguments and forwards rank 0's JSON line."""
+    import importlib
+    import subprocess
+    import types
+
+    bench = importlib.import_module("bench")
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4, 29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+    seen = {}
+
+    def fake_run(c, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = c, env
+        return types.SimpleNamespace(returncode=0, stdout='RCCL banner\n{"metric": "m", "value": 1.0, "n_gpus": 2}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    rc = bench.self_launch(["--gpus", "2"], 2)
+    out = capsys.readouterr()
+    assert rc == 0 and out.out.strip() == '{"metric": "m", "value": 1.0, "n_gpus": 2}'
+    assert "RCCL banner" in out.err  # library chatter goes to stderr, stdout carries the JSON line alone
+    assert seen["cmd"][-2:] == ["--gpus", "2"] and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    # a failing child: its status is ours, nothing on stdout
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=3, stdout="boom\n"))
+    assert bench.self_launch(["--gpus", "2"], 2) == 3
+    assert capsys.readouterr().out == ""
