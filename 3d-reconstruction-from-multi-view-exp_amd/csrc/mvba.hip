@@ -257,7 +257,7 @@ constexpr int PBS = 16;
 // the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
                                                    double *__restrict__ PB, int *__restrict__ flag,
-                                                   double *__restrict__ Ab, long long nAb) {
+                                                   double *__restrict__ Ab, long long nAb, int *__restrict__ prog, int nprog) {
   // a block's 256 points are 18 KiB of PL and 32 KiB of PB, both contiguous: moved with coalesced
   // accesses through LDS (a thread reading its own 72-byte row / writing its own 128-byte line touches
   // 64 different lines per instruction)
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
   __shared__ double2 s_out[256 * 8];
   const long long a0 = (long long)blockIdx.x * 256, a = a0 + threadIdx.x;
   for (long long i = a; i < nAb; i += (long long)gridDim.x * blockDim.x) Ab[i] = 0.0;
+  for (long long i = a; i < nprog; i += (long long)gridDim.x * blockDim.x) prog[i] = 0;  // pacing counters of k_schur_slots
   if (a0 >= npts) return;  // (uniform)
   const int np = (int)min<long long>(256, npts - a0);
   for (int e = threadIdx.x; e < 9 * np; e += 256) s_in[e] = PL[9 * a0 + e];
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
     out[1 ^ sw] = make_double2(i02, i11);
     out[2 ^ sw] = make_double2(i12, i22);
     out[3 ^ sw] = make_double2(i00 * g0 + i01 * g1 + i02 * g2, i01 * g0 + i11 * g1 + i12 * g2);
-    out[4 ^ sw] = make_double2(i02 * g0 + i12 * g1 + i22 * g2, 0.0);
+    out[4 ^ sw] = make_double2(i02 * g0 + i12 * g1 + i22 * g2, 1.0);  // tenth double: 1 = a point (row N, the padding row, stays 0)
     out[5 ^ sw] = out[6 ^ sw] = out[7 ^ sw] = make_double2(0.0, 0.0);
   }
   __syncthreads();
@@ -528,6 +529,8 @@ constexpr int PSTEP = 21;                       // items per wave step
 constexpr int PROW = 7 * 16;                    // staged bytes per record (slots 0..6, or 1..7)
 constexpr int PWAVE_LDS = PSTEP * (2 * PROW + 5 * 16);  // k rows, l rows, point rows
 constexpr int UNIT_STRIDE = 104;                // doubles per unit partial
+constexpr int SLOT_BUF = PSTEP * (2 * PROW + 3 * 16);  // slot form: one packed staging buffer (k rows, l rows, 48-byte point rows)
+constexpr int SLOT_LDS = 3 * SLOT_BUF;          // ... three of them per wave: 17,136 B, nine waves per CU
 
 __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_uniform) {
   __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
@@ -543,12 +546,25 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_unifo
 // per load, and so does a spilled register reloaded between two DMAs -- either drains the DMAs in
 // flight.  Only lane 63 of a record DMA is masked off (9 rows x 7 slots = 63 lanes; its 16 bytes
 // would land on the next chunk's first slot).
-template <bool DIAG, bool BIG>
+// Pacing of the slot-resident form (k_schur_slots): `seg_end[j]` = the step at which this wave has left segment j of
+// its point range, `prog[j]` = how many waves of the range have left segment j, `need` = how many there are.
+constexpr int PACE_STRIDE = 32;  // ints between two pacing counters: one 128-byte line each (they are hammered by ~300 waves)
+struct SlotPace {
+  const int *seg_end;
+  int *prog;
+  int need, nseg, lag;
+  long long *trace;  // diagnostic builds (-DMVBA_SLOT_TRACE): 8 words per wave
+};
+// SLOTS (the slot-resident form below, k_schur_slots): the 21 item rows of a step belong to 21 DIFFERENT lists, each
+// 3-lane slot keeps its own block for the whole run and writes it to its own partial (`out` is then the array of
+// partials and `slot_unit` the 21 unit ids of this wave); padding rows point at the all-zero record / point row.
+template <bool DIAG, bool BIG, bool SLOTS = false>
 __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, const long long beg, const int n,
                                                  const int *__restrict__ it_k, const int *__restrict__ it_l,
                                                  const int *__restrict__ it_a, const double2 *__restrict__ rec,
                                                  const double *__restrict__ PB, const double c, const double cu,
-                                                 double *__restrict__ out) {
+                                                 double *__restrict__ out, const int *__restrict__ slot_unit = nullptr,
+                                                 const SlotPace pace = SlotPace{nullptr, nullptr, 0, 0, 2, nullptr}) {
   constexpr int NPS = DIAG ? 5 : 3;                      // staged 16-byte slots of a point row
   const int it = lane / 3, cg = lane - 3 * it;           // compute: item of the step, column group
   const int drow = lane / 7, dslot = lane - 7 * drow;    // record DMA: 9 rows x 7 slots per instruction
@@ -565,8 +581,14 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     for (int q = 0; q < 3; ++q) acc[i][q] = 0.0;
   double dg[3] = {0.0, 0.0, 0.0}, rb[3] = {0.0, 0.0, 0.0};
 
-  int ixk[3], ixl[3], ixa[2];
-  auto load_idx = [&](int s0) {  // indices of the step starting at item s0 (to registers)
+  // staging buffer of one step: k rows | l rows (DIAG: the residual slots) | point rows.  The unit form keeps round
+  // 2's layout (two buffers of PWAVE_LDS); the slot form packs them (three buffers in a 9-waves-per-CU budget)
+  constexpr int LB_OFF = PSTEP * PROW;
+  constexpr int PB_OFF = LB_OFF + ((SLOTS && DIAG) ? PSTEP * 16 : PSTEP * PROW);
+  constexpr int BUFSZ = SLOTS ? PB_OFF + PSTEP * 16 * NPS : PWAVE_LDS;
+  static_assert(!SLOTS || BUFSZ <= SLOT_BUF, "slot form: staging buffer larger than the launch provides");
+  int ixk[2][3], ixl[2][3], ixa[2][2];  // two index register sets (the slot form keeps two steps' indices in flight)
+  auto load_idx = [&](int s0, int (&xk)[3], int (&xl)[3], int (&xa)[2]) {  // indices of the step starting at item s0 (to registers)
     // uniform base + unsigned 32-bit row: the saddr form again (written with int rows the clamps and the
     // address sums were done in 64 bits per lane: ~40 vector instructions per step for seven loads)
     // (the bases go through readfirstlane and the rows through an empty asm so that the compiler can neither
@@ -589,12 +611,12 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const unsigned row = row_of(9 * q + drow);
-      ixk[q] = at(pk, row);
-      if (!DIAG) ixl[q] = at(pl, row);
+      xk[q] = at(pk, row);
+      if (!DIAG) xl[q] = at(pl, row);
     }
-    if (DIAG) ixl[0] = at(pk, row_of(lane));  // the record whose residual slot this lane fetches
-    ixa[0] = at(pa, row_of(prow));
-    if (DIAG) ixa[1] = at(pa, row_of(prow2));
+    if (DIAG) xl[0] = at(pk, row_of(lane));  // the record whose residual slot this lane fetches
+    xa[0] = at(pa, row_of(prow));
+    if (DIAG) xa[1] = at(pa, row_of(prow2));
   };
   // Addresses as "uniform base + 32-bit byte offset" (the saddr form of the memory instructions: one
   // shift-add per address instead of a sign extension, a 64-bit shift and a 64-bit add); BIG: the
@@ -607,37 +629,30 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     if (BIG) return PB + (size_t)a * PBS + 2 * slot;
     return reinterpret_cast<const char *>(PB) + (((unsigned)a << 7) + ((unsigned)slot << 4));
   };
-  auto issue = [&](char *buf) {
-    char *kb = buf, *lb = buf + PSTEP * PROW, *pb_ = lb + PSTEP * PROW;
+  // (OFFDIAG: 7 DMA instructions, DIAG: 6 -- and as many index loads per step: the slot form's counted wait relies on it)
+  auto issue = [&](char *buf, const int (&xk)[3], const int (&xl)[3], const int (&xa)[2]) {
+    char *kb = buf, *lb = buf + LB_OFF, *pb_ = buf + PB_OFF;
     if (lane < 63) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        lds_dma16(rec_at(ixk[q], dslot), kb + q * (9 * PROW));
-        if (!DIAG) lds_dma16(rec_at(ixl[q], dslot), lb + q * (9 * PROW));
+        lds_dma16(rec_at(xk[q], dslot), kb + q * (9 * PROW));
+        if (!DIAG) lds_dma16(rec_at(xl[q], dslot), lb + q * (9 * PROW));
       }
-      if (!DIAG) lds_dma16(pb_at(ixa[0], pslot), pb_);
+      if (!DIAG) lds_dma16(pb_at(xa[0], pslot), pb_);
     }
     if (lane < 7 * (PSTEP - 18)) {  // third chunk: rows 18..20 only (a buffer holds 21 rows)
-      lds_dma16(rec_at(ixk[2], dslot), kb + 2 * (9 * PROW));
-      if (!DIAG) lds_dma16(rec_at(ixl[2], dslot), lb + 2 * (9 * PROW));
+      lds_dma16(rec_at(xk[2], dslot), kb + 2 * (9 * PROW));
+      if (!DIAG) lds_dma16(rec_at(xl[2], dslot), lb + 2 * (9 * PROW));
     }
     if (DIAG) {  // l-side == k-side: only the residual (slot 7) is fetched, 16 bytes per item
-      if (lane < PSTEP) lds_dma16(rec_at(ixl[0], 7), lb);
-      lds_dma16(pb_at(ixa[0], pslot), pb_);
-      if (lane < 5 * PSTEP - 64) lds_dma16(pb_at(ixa[1], pslot2), pb_ + 1024);
+      if (lane < PSTEP) lds_dma16(rec_at(xl[0], 7), lb);
+      lds_dma16(pb_at(xa[0], pslot), pb_);
+      if (lane < 5 * PSTEP - 64) lds_dma16(pb_at(xa[1], pslot2), pb_ + 1024);
     }
   };
-  load_idx(0);
-  issue(wbuf);
-  if (PSTEP < n) load_idx(PSTEP);
-  for (int s0 = 0, par = 0; s0 < n; s0 += PSTEP, par ^= 1) {
-    const int ns = min(PSTEP, n - s0);
-    char *kbuf = wbuf + par * PWAVE_LDS, *lbuf = kbuf + PSTEP * PROW, *pbuf = lbuf + PSTEP * PROW;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's rows have landed, the next step's indices too
-    if (s0 + PSTEP < n) {
-      issue(wbuf + (par ^ 1) * PWAVE_LDS);
-      if (s0 + 2 * PSTEP < n) load_idx(s0 + 2 * PSTEP);
-    }
+  // the arithmetic of one step on a landed buffer
+  auto compute = [&](const char *buf, const int ns) {
+    const char *kbuf = buf, *lbuf = buf + LB_OFF, *pbuf = buf + PB_OFF;
     if (it < ns) {
       const double2 *kr = reinterpret_cast<const double2 *>(kbuf + it * PROW);
       const double2 *lr = DIAG ? kr : reinterpret_cast<const double2 *>(lbuf + it * PROW);
@@ -652,9 +667,11 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
       double t00 = kx0.x * h0x + kx1.x * h1x + kx2.x * h2x, t01 = kx0.x * h0y + kx1.x * h1y + kx2.x * h2y;
       double t10 = kx0.y * h0x + kx1.y * h1x + kx2.y * h2x, t11 = kx0.y * h0y + kx1.y * h1y + kx2.y * h2y;
       double w0 = 0.0, w1 = 0.0;
+      // SLOTS: the point row's tenth double is 1 for a point and 0 for the padding row, whose G_k term must vanish too
+      const double wgt = (DIAG && SLOTS) ? pb[9] : 1.0;
       if (DIAG) {
-        t00 -= 0.5;
-        t11 -= 0.5;
+        t00 -= SLOTS ? 0.5 * wgt : 0.5;
+        t11 -= SLOTS ? 0.5 * wgt : 0.5;
         const double2 e = reinterpret_cast<const double2 *>(lbuf)[it];
         w0 = kx0.x * pb[6] + kx1.x * pb[7] + kx2.x * pb[8] - e.x;
         w1 = kx0.y * pb[6] + kx1.y * pb[7] + kx2.y * pb[8] - e.y;
@@ -677,13 +694,202 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
         acc[7][q] = fma(kw1.y, v1, fma(kw1.x, v0, acc[7][q]));
         acc[8][q] = fma(kw2.y, v1, fma(kw2.x, v0, acc[8][q]));
         if (DIAG) {
-          dg[q] += sx[q] * sx[q] + sy[q] * sy[q];
+          if (SLOTS) dg[q] = fma(wgt, sx[q] * sx[q] + sy[q] * sy[q], dg[q]);
+          else dg[q] += sx[q] * sx[q] + sy[q] * sy[q];
           rb[q] += sx[q] * w0 + sy[q] * w1;
         }
       }
     }
     // the LDS reads above are complete (their values were consumed) before this buffer is refilled
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // SLOTS pacing: the waves of a point range keep within `lag` segments of each other, so that what they gather at
+  // any moment fits their XCD's L2.  A performance hint only: a wave that waits too long (its siblings are not
+  // resident: somebody else holds the CUs) stops pacing and runs on.
+  bool pacing = SLOTS && pace.prog != nullptr;
+  int seg = 0, seg_stop = pacing ? as_const(pace.seg_end)[0] * PSTEP : 0x7fffffff;
+#ifdef MVBA_SLOT_TRACE
+  const long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+  long long tr_wait = 0, tr_blocked = 0, tr_polls = 0;
+#endif
+  auto pace_at = [&](const int s0) {
+    while (s0 == seg_stop) {  // (wave-uniform) this wave has left segment `seg`
+      if (lane == 0) __hip_atomic_fetch_add(pace.prog + PACE_STRIDE * seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++seg;
+      seg_stop = seg < pace.nseg ? as_const(pace.seg_end)[seg] * PSTEP : 0x7fffffff;
+#ifdef MVBA_SLOT_TRACE
+      const long long tr_a = __builtin_amdgcn_s_memrealtime();
+#endif
+      if (seg >= pace.lag && pacing) {  // nobody enters segment j before everybody has left segment j - lag
+        // (a waiting wave polls every ~3 us: hundreds of waves polling one word at full speed saturate the
+        // fabric's atomic path and slow the arrivals they are waiting for -- 15 ms per launch, measured)
+        int tries = 0;
+        while (__hip_atomic_fetch_add(pace.prog + PACE_STRIDE * (seg - pace.lag), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pace.need) {
+          if (++tries > 1024) { pacing = false; break; }  // ~2 ms: the siblings are not running
+          __builtin_amdgcn_s_sleep(127);  // (shorter sleeps, 48 / 16 / 4: 1.69 / 1.70 / 1.71 ms against 1.67)
+        }
+        // a wave that had to wait is ahead of the pack, one that did not is among those the pack waits for: the
+        // SIMD's issue arbitration (priority, then age) should favour the latter (1.71 -> 1.62 ms together with
+        // dispatching the diagonal waves first; three priority levels or none: no better / 1.73)
+        if (tries > 0) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+#ifdef MVBA_SLOT_TRACE
+        tr_polls += tries + 1;
+        tr_blocked += tries > 0;
+#endif
+      }
+#ifdef MVBA_SLOT_TRACE
+      tr_wait += __builtin_amdgcn_s_memrealtime() - tr_a;
+#endif
+    }
+  };
+  if (!SLOTS) {
+    load_idx(0, ixk[0], ixl[0], ixa[0]);
+    issue(wbuf, ixk[0], ixl[0], ixa[0]);
+    if (PSTEP < n) load_idx(PSTEP, ixk[0], ixl[0], ixa[0]);
+    for (int s0 = 0, par = 0; s0 < n; s0 += PSTEP, par ^= 1) {
+      const int ns = min(PSTEP, n - s0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's rows have landed, the next step's indices too
+      if (s0 + PSTEP < n) {
+        issue(wbuf + (par ^ 1) * BUFSZ, ixk[0], ixl[0], ixa[0]);
+        if (s0 + 2 * PSTEP < n) load_idx(s0 + 2 * PSTEP, ixk[0], ixl[0], ixa[0]);
+      }
+      compute(wbuf + par * BUFSZ, ns);
+    }
+  } else {
+    // Three buffers, the gathers of TWO steps in flight: a wave of this form is one serial chain of ~1400 steps
+    // for the whole launch and 9 of them share a CU, so what bounds it is steps-in-flight x latency, not
+    // throughput (per-wave stamps: 1.18 us per step with one step in flight, every wave alike).
+    // Order of the vector-memory operations: iteration s issues the gather of step s + 2 and then loads the
+    // indices of step s + 4 into the register set that gather has just freed; vmcnt retires in issue order, so
+    // "all but the last iteration's operations" (`SLOT_OPS` of them: every gather and index load is
+    // unconditional, steps past the end are clamped to the last one) = step s has landed and the indices of
+    // step s + 2 are in their registers, while step s + 1 and the indices of s + 3 stay in flight.
+    // hipcc cannot be left to count these waits: it drains the queue (vmcnt(0)) before the first use of an index
+    // register that an ordinary load fills, and before LDS reads that might alias a gather in flight.  So in this
+    // loop every vector-memory operation is inline assembly the compiler knows nothing about, and the counted
+    // waits below are the only ones; each wait names the index registers it releases as in/out operands, so that
+    // no use of them can be scheduled above it.
+    constexpr int SLOT_OPS = DIAG ? 12 : 14;
+    const int last0 = n - PSTEP;  // first item of the last step
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)wbuf;
+    const unsigned rowk0 = (unsigned)min(drow, PSTEP - 1) << 2, rowk1 = (unsigned)min(9 + drow, PSTEP - 1) << 2,
+                   rowk2 = (unsigned)min(18 + drow, PSTEP - 1) << 2;  // byte offsets of this lane's index rows
+    const unsigned rowa0 = (unsigned)min(prow, PSTEP - 1) << 2, rowa1 = (unsigned)min(prow2, PSTEP - 1) << 2;
+    const unsigned rowl = (unsigned)min(lane, PSTEP - 1) << 2;
+    auto gld = [](int &dst, unsigned off, const int *base) {
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+    };
+    auto load_idx_asm = [&](int s0, int (&xk)[3], int (&xl)[3], int (&xa)[2]) {
+      const int *pk = it_k + (beg + s0), *pl = it_l + (beg + s0), *pa = it_a + (beg + s0);  // (wave-uniform: SGPR pairs)
+      gld(xk[0], rowk0, pk); gld(xk[1], rowk1, pk); gld(xk[2], rowk2, pk);
+      if (!DIAG) { gld(xl[0], rowk0, pl); gld(xl[1], rowk1, pl); gld(xl[2], rowk2, pl); }
+      else gld(xl[0], rowl, pk);
+      gld(xa[0], rowa0, pa);
+      if (DIAG) gld(xa[1], rowa1, pa);
+    };
+    // (32-bit byte offsets only: with 64-bit per-lane addresses this loop needs more than the 168 registers of
+    // three waves per SIMD, and a spill's scratch access would be a vector-memory operation the counted waits do
+    // not know about -- scenes whose records span 4 GiB run the unit form, mvba_create sees to that)
+    static_assert(!SLOTS || !BIG, "the slot form has no 64-bit-offset build");
+    auto dma = [&](int row, unsigned slot16, const void *base, unsigned lds) {  // 16 bytes per lane: base[row * 128 + slot16] -> LDS
+      const unsigned o = ((unsigned)row << 7) + slot16;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");
+    };
+    const unsigned ds16 = (unsigned)dslot << 4, ps16 = (unsigned)pslot << 4, ps16b = (unsigned)pslot2 << 4;
+    auto issue_asm = [&](unsigned buf, const int (&xk)[3], const int (&xl)[3], const int (&xa)[2]) {
+      const unsigned kb = buf, lb = buf + LB_OFF, pb_ = buf + PB_OFF;
+      if (lane < 63) {
+        dma(xk[0], ds16, rec, kb);
+        if (!DIAG) dma(xl[0], ds16, rec, lb);
+        dma(xk[1], ds16, rec, kb + 9 * PROW);
+        if (!DIAG) dma(xl[1], ds16, rec, lb + 9 * PROW);
+        if (!DIAG) dma(xa[0], ps16, PB, pb_);
+      }
+      if (lane < 7 * (PSTEP - 18)) {
+        dma(xk[2], ds16, rec, kb + 18 * PROW);
+        if (!DIAG) dma(xl[2], ds16, rec, lb + 18 * PROW);
+      }
+      if (DIAG) {
+        if (lane < PSTEP) dma(xl[0], 7u << 4, rec, lb);
+        dma(xa[0], ps16, PB, pb_);
+        if (lane < 5 * PSTEP - 64) dma(xa[1], ps16b, PB, pb_ + 1024);
+      }
+    };
+    auto wait_set = [&](int (&xk)[3], int (&xl)[3], int (&xa)[2], bool all) {
+      if (all)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
+      else if (DIAG)
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(14)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // (registers the asm operands name must be initialised)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ixk[u][q] = ixl[u][q] = 0;
+      ixa[u][0] = ixa[u][1] = 0;
+    }
+    load_idx_asm(0, ixk[0], ixl[0], ixa[0]);
+    load_idx_asm(min(PSTEP, last0), ixk[1], ixl[1], ixa[1]);
+    wait_set(ixk[0], ixl[0], ixa[0], true);
+    wait_set(ixk[1], ixl[1], ixa[1], true);
+    issue_asm(lds0, ixk[0], ixl[0], ixa[0]);
+    load_idx_asm(min(2 * PSTEP, last0), ixk[0], ixl[0], ixa[0]);
+    issue_asm(lds0 + BUFSZ, ixk[1], ixl[1], ixa[1]);
+    load_idx_asm(min(3 * PSTEP, last0), ixk[1], ixl[1], ixa[1]);
+    int slot = 0;  // ring position of step s0
+    for (int s0 = 0; s0 < n; s0 += 2 * PSTEP) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // (unrolled by two: the index register sets alternate)
+        const int s = s0 + u * PSTEP;
+        if (s < n) {  // (wave-uniform)
+          wait_set(ixk[u], ixl[u], ixa[u], false);  // step s has landed, the indices of step s + 2 are in set u
+          pace_at(s);
+          const int nxt = slot == 0 ? 2 : slot - 1;  // (s + 2) % 3
+          issue_asm(lds0 + nxt * BUFSZ, ixk[u], ixl[u], ixa[u]);
+          load_idx_asm(min(s + 4 * PSTEP, last0), ixk[u], ixl[u], ixa[u]);
+          compute(wbuf + slot * BUFSZ, PSTEP);
+          slot = slot == 2 ? 0 : slot + 1;
+        }
+      }
+    }
+    static_assert(SLOT_OPS == (DIAG ? 12 : 14), "counted wait");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped gathers still in flight land in this wave's LDS
+  }
+  // J_C row i = rs_i * (record columns): f | u,v (1/f0) | t (-Jx) | omega; the same factors per column
+  const double cs0 = cg == 1 ? -1.0 : 1.0, cs12 = cg == 0 ? cu : cs0;
+  if (SLOTS) {  // every slot holds a finished block of its own: no sum over lanes
+    if (pace.prog != nullptr && lane == 0)
+      for (; seg < pace.nseg; ++seg) __hip_atomic_fetch_add(pace.prog + PACE_STRIDE * seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MVBA_SLOT_TRACE
+    if (pace.trace && lane == 0) {
+      int hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+      pace.trace[0] = tr_t0; pace.trace[1] = __builtin_amdgcn_s_memrealtime(); pace.trace[2] = tr_wait; pace.trace[3] = tr_blocked;
+      pace.trace[4] = tr_polls; pace.trace[5] = hwid; pace.trace[6] = xcc; pace.trace[7] = n / PSTEP;
+    }
+#endif
+    const int u = it < PSTEP ? slot_unit[it] : -1;
+    if (u >= 0) {
+      double *o = out + (size_t)u * UNIT_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double rs = (i == 1 || i == 2) ? cu : ((i >= 3 && i < 6) ? -1.0 : 1.0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) o[9 * i + 3 * cg + q] = -4.0 * rs * (q == 0 ? cs0 : cs12) * acc[i][q];
+      }
+      if (DIAG) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const double cs = q == 0 ? cs0 : cs12;
+          o[81 + 3 * cg + q] = 2.0 * c * cs * cs * dg[q];
+          o[90 + 3 * cg + q] = 2.0 * cs * rb[q];
+        }
+      }
+    }
+    return;
   }
   // ---- sum over the 21 item lanes of each column group (fixed tree), lanes 0..2 write the partial
   auto tree = [&](double v) {
@@ -694,8 +900,6 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     }
     return v;
   };
-  // J_C row i = rs_i * (record columns): f | u,v (1/f0) | t (-Jx) | omega; the same factors per column
-  const double cs0 = cg == 1 ? -1.0 : 1.0, cs12 = cg == 0 ? cu : cs0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const double rs = (i == 1 || i == 2) ? cu : ((i >= 3 && i < 6) ? -1.0 : 1.0);
@@ -776,6 +980,68 @@ __global__ __launch_bounds__(64, 3) void k_schur_pairs_big(MVBA_PAIRS_ARGS) {  /
   schur_pairs_wave<true>(units, q_ptr, q_units, head, it_k, it_l, it_a, rec, PB, c, f0, partial);
 }
 
+// ------------------------------------------------------------------ K3 (slot-resident form)
+// The pair-major kernel above reads every record ~5 times from beyond its L2 (89 M line misses for 10 M records at
+// config 3): a unit sweeps 1/16 of the points for ONE pair, so what the ~300 units in flight on an XCD touch at
+// any moment is spread over 80 MB of records.  Here the roles of the 21 item rows of a step are transposed:
+//   slot     a 3-lane slot (item row `it`) owns ONE list -- the items of one (pair, sub-list) inside one point
+//            range -- for the whole launch and keeps that pair's 9x9 block in its 27 registers per lane: still no
+//            scatter, no atomic, no cross-lane sum at all (the fixed-order tree is gone), one partial per list
+//   range    the points are cut into 8 ranges of equal item count, range r = the blocks b with b % 8 == r = XCD r
+//            under the round-robin block placement (locality only, never correctness): a record is needed by ONE
+//            XCD, and ALL lists of the range (m (m+1) / 2 pairs + the diagonal pairs' sub-lists: 5.9 k slots =
+//            284 waves at m = 100) are resident on that XCD at once and sweep the range's points together
+//   steps    built once on the host (mvba_create): the 21 lists of a wave are merged into steps with a bounded skew --
+//            a slot whose next item lies more than `skew` observations ahead of the wave's slowest slot idles
+//            for a step (its row points at the all-zero record / point row: the arithmetic runs and adds
+//            exact zeros) -- so that what a wave touches at any moment fits its XCD's L2 next to its siblings'
+// Same staging (LDS-DMA of whole lines), same arithmetic and the same partial -> k_schur_reduce path as above.
+__device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc, const int *__restrict__ wunits,
+                                                 const int *__restrict__ it_k, const int *__restrict__ it_l,
+                                                 const int *__restrict__ it_a, const double2 *__restrict__ rec,
+                                                 const double *__restrict__ PB, double c, double f0,
+                                                 double *__restrict__ partial, int *__restrict__ head, int nR, int wpr,
+                                                 const int *__restrict__ seg_end, int *__restrict__ prog, int nseg, int lag,
+                                                 long long *__restrict__ trace) {
+  extern __shared__ char smem_pairs[];
+  // which wave of which range: static (head == nullptr) block b IS wave b / nR of range b % nR; dynamic: the wave
+  // reads the XCD it runs on and takes the next wave of a range of that XCD (r % 8 == XCC_ID), then of the others
+  int bid = blockIdx.x;
+  if (head) {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    bid = -1;
+    if (threadIdx.x == 0) {
+      for (int t = 0; t < nR && bid < 0; ++t) {
+        const int r = ((xcc & 7) + t) % nR;
+        const int q = atomicAdd(&head[r], 1);
+        if (q < wpr) bid = nR * q + r;
+      }
+    }
+    bid = __builtin_amdgcn_readfirstlane(bid);
+    if (bid < 0) return;
+  }
+  const int MVBA_CONST_AS *dp = as_const(reinterpret_cast<const int *>(wdesc)) + 4 * (size_t)bid;
+  const int d_x = dp[0], d_y = dp[1], nsteps = dp[2], flags = dp[3];
+  if (nsteps <= 0) return;  // (wave-uniform) a wave whose lists are all empty in this range: no units, nothing to write
+  const long long beg = ((long long)d_y << 32) | (unsigned)d_x;
+  const int *su = wunits + (size_t)bid * PSTEP;
+  SlotPace pace{nullptr, nullptr, 0, 0, 2, trace ? trace + 8 * (size_t)bid : nullptr};
+  if (prog) pace = SlotPace{seg_end + (size_t)bid * nseg, prog + (size_t)(bid % nR) * nseg * PACE_STRIDE, flags >> 8, nseg, lag, pace.trace};
+  if (flags & 1)
+    schur_pairs_unit<true, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, partial, su, pace);
+  else
+    schur_pairs_unit<false, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, partial, su, pace);
+}
+#define MVBA_SLOTS_ARGS                                                                                                  \
+  const int4 *__restrict__ wdesc, const int *__restrict__ wunits, const int *__restrict__ it_k, const int *__restrict__ it_l, \
+      const int *__restrict__ it_a, const double2 *__restrict__ rec, const double *__restrict__ PB, double c, double f0,  \
+      double *__restrict__ partial, int *__restrict__ head, int nR, int wpr, const int *__restrict__ seg_end,            \
+      int *__restrict__ prog, int nseg, int lag, long long *__restrict__ trace
+__global__ __launch_bounds__(64, 3) void k_schur_slots(MVBA_SLOTS_ARGS) {
+  schur_slots_wave(wdesc, wunits, it_k, it_l, it_a, rec, PB, c, f0, partial, head, nR, wpr, seg_end, prog, nseg, lag, trace);
+}
+
 // One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
 // One block per PAIR (blockIdx.x = packed pair index); the partials are loaded eight at a time (one
 // memory latency per eight units instead of one per unit: a diagonal pair has ~130 of them) and
@@ -783,7 +1049,7 @@ __global__ __launch_bounds__(64, 3) void k_schur_pairs_big(MVBA_PAIRS_ARGS) {  /
 __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restrict__ unit_ptr,
                                                       const double *__restrict__ partial, double *__restrict__ Afull,
                                                       double *__restrict__ bfull, int *__restrict__ head) {
-  if (blockIdx.x == 0 && threadIdx.x < 8) head[threadIdx.x] = 0;  // work queues for the next launch
+  if (blockIdx.x == 0 && threadIdx.x < 64) head[threadIdx.x] = 0;  // work queues for the next launch
   // pair index -> (k, l): pairs of strip k start at k m - k (k - 1) / 2
   const long long p = blockIdx.x;
   int k = (int)((2.0 * m + 1.0 - sqrt((2.0 * m + 1.0) * (2.0 * m + 1.0) - 8.0 * (double)p)) * 0.5);
@@ -1877,6 +2143,7 @@ __global__ __launch_bounds__(256) void k_similarity(long long npts, int m, doubl
 }  // namespace
 
 // ------------------------------------------------------------------ host side
+enum { SCHUR_STRIP = 0, SCHUR_PAIRS = 1, SCHUR_SLOTS = 2 };
 struct mvba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1894,9 +2161,22 @@ struct mvba_handle {
   long long *d_chunk_ptr = nullptr;
   int nchunks = 1, lseg = 0, nseg = 1, schur_threads = 768, k1_threads = 512;
   // pair-major Schur index (k_schur_pairs): items sorted by (k, l, point), units, per-XCD work queues
-  bool use_pairs = true;
-  long long n_items = 0, n_items_offdiag = 0;
-  int n_units = 0, rccl_version = 0, q_max = 0;
+  bool use_pairs = true;              // pair-major index present (schur_mode != SCHUR_STRIP)
+  int schur_mode = 2;                 // SCHUR_STRIP / SCHUR_PAIRS / SCHUR_SLOTS (see k_schur_slots)
+  long long slot_skew = 12288;        // bounded skew of the slot form's step merge, in observations
+  long long slot_window = 1LL << 40;  // ... and the window in which all waves of a range take equally many steps (off)
+  long long n_items = 0, n_items_offdiag = 0, n_slot_items = 0;
+  int n_units = 0, rccl_version = 0, q_max = 0, n_waves = 0, slot_nR = 8, slot_nseg = 0;
+  long long slot_seg = 8192;          // pacing segment of the slot form, in observations
+  bool slot_pace = true;
+  int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
+  int *d_seg_end = nullptr, *d_prog = nullptr;
+  long long *d_trace = nullptr;       // -DMVBA_SLOT_TRACE builds with MVBA_SLOT_TRACE=<file>: per-wave timings of the last launch
+  int4 *d_wdesc = nullptr;
+  int *d_wunits = nullptr;
+  // experiment knobs, read from the environment ONCE in mvba_create (tools/README.md lists them)
+  bool pair_static = true, force_big = false;
+  int backsub_lanes = 0;
   int *d_it_k = nullptr, *d_it_l = nullptr, *d_it_a = nullptr, *d_unit_ptr = nullptr, *d_q_ptr = nullptr, *d_q_units = nullptr,
       *d_q_head = nullptr;
   int4 *d_units = nullptr;
@@ -2163,10 +2443,19 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
 
   // ---- pair-major Schur index (see k_schur_pairs).  Items (obs of k, obs of l, point) for every
   // pair k <= l of a point's cameras, counting-sorted by pair, ascending point inside a pair.
-  if (const char *ev = getenv("MVBA_SCHUR")) h->use_pairs = strcmp(ev, "strip") != 0;
-  if (m > 65535) h->use_pairs = false;
-  std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units;
-  std::vector<int4> units;
+  if (const char *ev = getenv("MVBA_SCHUR"))
+    h->schur_mode = !strcmp(ev, "strip") ? SCHUR_STRIP : (!strcmp(ev, "pairs") ? SCHUR_PAIRS : SCHUR_SLOTS);
+  if (const char *ev = getenv("MVBA_SLOT_SKEW")) h->slot_skew = std::max(0LL, atoll(ev));
+  if (const char *ev = getenv("MVBA_SLOT_WINDOW")) h->slot_window = std::max(1LL, atoll(ev));
+  if (const char *ev = getenv("MVBA_SLOT_LAG")) h->slot_lag = std::max(1, atoi(ev));
+  if (const char *ev = getenv("MVBA_SLOT_SEG")) { h->slot_seg = std::max(1LL, atoll(ev)); h->slot_pace = atoll(ev) > 0; }
+  if (const char *ev = getenv("MVBA_PAIR_STATIC")) h->pair_static = atoi(ev) != 0;
+  if (const char *ev = getenv("MVBA_BACKSUB_LANES")) h->backsub_lanes = atoi(ev);
+  h->force_big = getenv("MVBA_FORCE_BIG") != nullptr;
+  if (m > 65535) h->schur_mode = SCHUR_STRIP;
+  h->use_pairs = h->schur_mode != SCHUR_STRIP;
+  std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units, st_k, st_l, st_a, wunits, seg_end;
+  std::vector<int4> units, wdesc;
   if (h->use_pairs) {
     const long long P = (long long)m * (m + 1) / 2;
     auto pair_id = [m](int k, int l) { return (long long)k * m - (long long)k * (k - 1) / 2 + (l - k); };
@@ -2211,9 +2500,42 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       vp_ptr[q + 1] = vp_ptr[q] + S[q];
     }
     const int VP = vp_ptr[P];
-    // point ranges per list: long runs for big problems, but small ones still get ~4096 units of >= 128 items
-    const long long nR_big = (target + unit_items / 2) / unit_items, nR_fill = std::min<long long>((4096 + VP - 1) / VP, target / 128);
-    const int nR = (int)std::max<long long>(1, std::min<long long>(64, std::max(nR_big, nR_fill)));
+    // ---- which form of the kernel: the slot-resident one (k_schur_slots) needs all lists of a point range resident on
+    // one XCD at once -- 9 waves per CU (LDS) x n_cu / 8 CUs x 21 slots = 6048 lists: up to 100 cameras at 10 %
+    // visibility (4950 pairs + ~1000 sub-lists of the diagonal pairs); beyond that the unit form runs
+    int n_off_lists = 0, n_diag_lists = 0;
+    for (int k = 0; k < m; ++k)
+      for (int l = k; l < m; ++l) (k == l ? n_diag_lists : n_off_lists) += S[pair_id(k, l)];
+    const int wpr = (n_off_lists + PSTEP - 1) / PSTEP + (n_diag_lists + PSTEP - 1) / PSTEP;  // waves per range
+    int n_cu_dev = 256;
+    hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, h->device);
+    const int xcd_waves = std::max(1, n_cu_dev / 8) * (160 * 1024 / SLOT_LDS);  // 9 waves of 17,136 B of LDS per CU
+    if (h->schur_mode == SCHUR_SLOTS && (wpr > xcd_waves || (std::max(nobs, N) + 1) * 128LL >= (1LL << 32) || h->force_big))
+      h->schur_mode = SCHUR_PAIRS;
+    const bool slots = h->schur_mode == SCHUR_SLOTS;
+    // point ranges.  Unit form: long runs for big problems, but small ones still get ~4096 units of >= 128 items.
+    // Slot form: 8 ranges (one per XCD) -- 8 j while j ranges' worth of waves fit an XCD and a list keeps >= 64 items.
+    int nR;
+    if (slots) {
+      const long long j = std::max<long long>(1, std::min<long long>(xcd_waves / wpr, target / (8 * 64)));
+      nR = (int)(8 * std::min<long long>(j, 8));
+    } else {
+      const long long nR_big = (target + unit_items / 2) / unit_items, nR_fill = std::min<long long>((4096 + VP - 1) / VP, target / 128);
+      nR = (int)std::max<long long>(1, std::min<long long>(64, std::max(nR_big, nR_fill)));
+    }
+    std::vector<long long> range_lo(nR + 1);
+    if (slots) {  // equal ITEM counts: the ranges run side by side, one per XCD
+      std::vector<long long> pre(N + 1, 0);
+      for (long long a = 0; a < N; ++a) {
+        const long long d = p->pt_ptr[a + 1] - p->pt_ptr[a];
+        pre[a + 1] = pre[a] + d * (d + 1) / 2;
+      }
+      for (int r = 0; r <= nR; ++r)
+        range_lo[r] = std::lower_bound(pre.begin(), pre.end(), (long long)((__int128)pre[N] * r / nR)) - pre.begin();
+      range_lo[0] = 0; range_lo[nR] = N;
+    } else {
+      for (int r = 0; r <= nR; ++r) range_lo[r] = (long long)((__int128)N * r / nR);
+    }
     std::vector<long long> vp_off(VP + 1, 0);
     for (long long q = 0; q < P; ++q)
       for (int sI = 0; sI < S[q]; ++sI) vp_off[vp_ptr[q] + sI + 1] = (cnt[q] - sI + S[q] - 1) / S[q];
@@ -2250,8 +2572,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
           const int v = vp_ptr[q] + sI;
           const int *b = it_a.data() + vp_off[v], *e = it_a.data() + vp_off[v + 1];
           for (int r = 0; r < nR; ++r) {
-            const long long a_lo = (long long)((__int128)N * r / nR), a_hi = (long long)((__int128)N * (r + 1) / nR);
-            const long long lo = std::lower_bound(b, e, a_lo) - it_a.data(), hi = std::lower_bound(b, e, a_hi) - it_a.data();
+            const long long lo = std::lower_bound(b, e, range_lo[r]) - it_a.data(), hi = std::lower_bound(b, e, range_lo[r + 1]) - it_a.data();
             if (hi <= lo) continue;
             uid[(size_t)v * nR + r] = (int)units.size();
             units.push_back(make_int4((int)(lo & 0xffffffffLL), (int)(lo >> 32), (int)(hi - lo), (k << 16) | l));
@@ -2259,6 +2580,144 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
       }
     unit_ptr[P] = (int)units.size();
+    if (slots) {
+      // ---- waves of 21 lists (off-diagonal lists first, then the diagonal pairs' sub-lists), every wave once per range
+      std::vector<int> lists_off, lists_diag;  // list ids v = vp_ptr[pair] + sub-list
+      for (int k = 0; k < m; ++k)
+        for (int l = k; l < m; ++l) {
+          const long long q = pair_id(k, l);
+          for (int sI = 0; sI < S[q]; ++sI) (k == l ? lists_diag : lists_off).push_back(vp_ptr[q] + sI);
+        }
+      const int w_off = (int)((lists_off.size() + PSTEP - 1) / PSTEP);
+      const long long n_waves = (long long)wpr * nR;
+      wdesc.assign(n_waves, make_int4(0, 0, 0, 0));
+      wunits.assign((size_t)n_waves * PSTEP, -1);
+      std::vector<long long> w_steps(n_waves, 0), w_beg(n_waves + 1, 0);
+      // block b = nR w + r: wave w of range r runs on XCD r % 8
+      // (the diagonal waves come FIRST: a CU's SIMDs arbitrate by age, the blocks dispatched last share a SIMD three
+      // ways as its youngest wave and fall behind -- and a diagonal step is the dearer one)
+      const int w_diag = wpr - w_off;
+      auto wave_lists = [&](long long b, int *vs) {  // the 21 list ids of block b (-1: none); returns the range
+        const int w = (int)(b / nR);
+        const bool dg = w < w_diag;
+        const std::vector<int> &src = dg ? lists_diag : lists_off;
+        const size_t first = (size_t)(dg ? w : w - w_diag) * PSTEP;
+        for (int sl = 0; sl < PSTEP; ++sl) vs[sl] = first + sl < src.size() ? src[first + sl] : -1;
+        return (int)(b % nR);
+      };
+      // Bounded-skew merge of a wave's lists into steps (see k_schur_slots), window by window: the observations of a
+      // range are cut into windows of `slot_window`, and every wave of the range is padded to the same number of
+      // steps per window (the slowest wave's), so that all waves of an XCD reach a window boundary at the same step
+      // index and cannot drift apart by more than their rate difference inside one window.
+      const long long skew = h->slot_skew, window = std::max<long long>(1, h->slot_window);
+      int nWin = 1;
+      for (int r = 0; r < nR; ++r)
+        nWin = std::max<long long>(nWin, (p->pt_ptr[range_lo[r + 1]] - p->pt_ptr[range_lo[r]] + window - 1) / window);
+      const bool equalize = h->slot_window < (1LL << 39);
+      std::vector<int> win_steps((size_t)n_waves * nWin, 0), win_max((size_t)nR * nWin, 0);
+      // pacing segments: seg_end[b][j] = steps wave b has taken when its slowest slot leaves segment j of the range
+      const long long segG = std::max<long long>(1, h->slot_seg);
+      int nSeg = 1;
+      for (int r = 0; r < nR; ++r)
+        nSeg = std::max<long long>(nSeg, (p->pt_ptr[range_lo[r + 1]] - p->pt_ptr[range_lo[r]] + segG - 1) / segG);
+      seg_end.assign((size_t)n_waves * nSeg, 0);
+      h->slot_nseg = nSeg;
+      auto merge = [&](long long b, long long base, bool fill) {
+        int vs[PSTEP];
+        const int r = wave_lists(b, vs);
+        long long cur[PSTEP], end[PSTEP];
+        for (int sl = 0; sl < PSTEP; ++sl) {
+          const int id = vs[sl] >= 0 ? uid[(size_t)vs[sl] * nR + r] : -1;
+          if (id < 0) { cur[sl] = end[sl] = 0; continue; }
+          cur[sl] = ((long long)units[id].y << 32) | (unsigned)units[id].x;
+          end[sl] = cur[sl] + units[id].z;
+          if (fill) wunits[(size_t)b * PSTEP + sl] = id;
+        }
+        long long steps = 0;
+        const long long o_lo = p->pt_ptr[range_lo[r]];
+        int sg = 0;
+        for (int j = 0; j < nWin; ++j) {
+          const long long limit = j + 1 < nWin ? o_lo + (j + 1) * window : (1LL << 62);
+          long long ws = 0;
+          while (true) {
+            long long lo = -1;
+            for (int sl = 0; sl < PSTEP; ++sl)
+              if (cur[sl] < end[sl] && it_k[cur[sl]] < limit && (lo < 0 || it_k[cur[sl]] < lo)) lo = it_k[cur[sl]];
+            if (fill && lo >= 0)
+              while (sg < nSeg && lo >= o_lo + (sg + 1) * segG) seg_end[(size_t)b * nSeg + sg++] = (int)(steps + ws);
+            if (lo < 0) break;
+            for (int sl = 0; sl < PSTEP; ++sl) {
+              const bool take = cur[sl] < end[sl] && it_k[cur[sl]] < limit && it_k[cur[sl]] <= lo + skew;
+              if (fill) {
+                const long long o = (base + steps + ws) * PSTEP + sl;
+                if (take) { st_k[o] = it_k[cur[sl]]; st_l[o] = it_l[cur[sl]]; st_a[o] = it_a[cur[sl]]; }
+                else { st_k[o] = st_l[o] = (int)nobs; st_a[o] = (int)N; }  // the all-zero record and point row
+              }
+              if (take) ++cur[sl];
+            }
+            ++ws;
+          }
+          if (!fill) { win_steps[(size_t)b * nWin + j] = (int)ws; steps += ws; continue; }
+          const long long target_ws = equalize ? win_max[(size_t)r * nWin + j] : ws;
+          for (; ws < target_ws; ++ws)
+            for (int sl = 0; sl < PSTEP; ++sl) {
+              const long long o = (base + steps + ws) * PSTEP + sl;
+              st_k[o] = st_l[o] = (int)nobs; st_a[o] = (int)N;
+            }
+          steps += target_ws;
+        }
+        if (fill)
+          while (sg < nSeg) seg_end[(size_t)b * nSeg + sg++] = (int)steps;
+        return steps;
+      };
+      on_threads([&](int tid) {
+        for (long long b = tid; b < n_waves; b += n_thr) merge(b, 0, false);
+      });
+      for (long long b = 0; b < n_waves; ++b)
+        for (int j = 0; j < nWin; ++j) {
+          int &mx = win_max[(size_t)(b % nR) * nWin + j];
+          mx = std::max(mx, win_steps[(size_t)b * nWin + j]);
+        }
+      for (long long b = 0; b < n_waves; ++b) {
+        long long t = 0;
+        bool any = false;
+        for (int j = 0; j < nWin; ++j) {
+          t += equalize ? win_max[(size_t)(b % nR) * nWin + j] : win_steps[(size_t)b * nWin + j];
+          any |= win_steps[(size_t)b * nWin + j] > 0;
+        }
+        w_steps[b] = any ? t : 0;  // a wave without any item does not run at all
+      }
+      for (long long b = 0; b < n_waves; ++b) w_beg[b + 1] = w_beg[b] + w_steps[b];
+      const long long total_steps = w_beg[n_waves];
+      if (total_steps * PSTEP >= (1LL << 40)) { mvba_destroy(h); return fail(MVBA_ERR_BADARG, "too many (point, camera pair) items"); }
+      st_k.resize(total_steps * PSTEP); st_l.resize(total_steps * PSTEP); st_a.resize(total_steps * PSTEP);
+      on_threads([&](int tid) {
+        for (long long b = tid; b < n_waves; b += n_thr)
+          if (w_steps[b]) merge(b, w_beg[b], true);
+      });
+      const int w_off_ = w_off;
+      std::vector<int> live(nR, 0);  // waves of a range that run at all: what a pacing counter has to reach
+      for (long long b = 0; b < n_waves; ++b) live[b % nR] += w_steps[b] > 0;
+      for (long long b = 0; b < n_waves; ++b) {
+        const long long beg = w_beg[b] * PSTEP;
+        wdesc[b] = make_int4((int)(beg & 0xffffffffLL), (int)(beg >> 32), (int)w_steps[b],
+                             ((int)(b / nR) < wpr - w_off_ ? 1 : 0) | (live[b % nR] << 8));
+      }
+      h->n_waves = (int)n_waves;
+      h->slot_nR = nR;
+#ifdef MVBA_SLOT_TRACE
+      if (const char *ev = getenv("MVBA_SLOT_DUMP"))  // diagnostic build: the pacing table (steps at each segment boundary)
+        if (FILE *f = fopen(ev, "wb")) {
+          const int hdr[4] = {(int)n_waves, nSeg, nR, wpr};
+          fwrite(hdr, sizeof(int), 4, f);
+          fwrite(seg_end.data(), sizeof(int), seg_end.size(), f);
+          fclose(f);
+        }
+#endif
+      h->n_slot_items = total_steps * PSTEP;
+      it_k.swap(st_k); it_l.swap(st_l); it_a.swap(st_a);  // what is uploaded below: the step-major arrays
+      std::vector<int>().swap(st_k); std::vector<int>().swap(st_l); std::vector<int>().swap(st_a);
+    } else {
     // work queues: strip k on XCD k % 8, inside a queue by (k, range, l, sub-list)
     // range-major: every XCD sweeps the point ranges in the same order, so the l-side records of
     // a range (needed once per strip, ~4.5 times in all) are re-read from the Infinity Cache while
@@ -2283,6 +2742,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       }
       q_ptr[x + 1] = (int)q_units.size();
     }
+    }
     h->n_items = T;
     h->n_items_offdiag = T - Tdiag;
     h->n_units = (int)units.size();
@@ -2303,9 +2763,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_tiles, tiles.size()));
   TRY(dmalloc(&h->d_chunk_ptr, chunk_ptr.size()));
   for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
-  TRY(dmalloc(&h->d_rec, (size_t)REC * nobs));
+  TRY(dmalloc(&h->d_rec, (size_t)REC * (nobs + 1)));  // + the all-zero record and point row the slot form's padding points at
   TRY(dmalloc(&h->d_PL, 9 * N));
-  TRY(dmalloc(&h->d_PB, (size_t)PBS * N));
+  TRY(dmalloc(&h->d_PB, (size_t)PBS * (N + 1)));
+  TRYH(hipMemset(h->d_rec + (size_t)REC * nobs, 0, sizeof(double2) * REC));
+  TRYH(hipMemset(h->d_PB + (size_t)PBS * N, 0, sizeof(double) * PBS));
   const size_t n9 = 9 * (size_t)m;
   TRY(dmalloc(&h->d_Ab, strip_offset(m, m) + n9));
   TRY(dmalloc(&h->d_Ared, (size_t)(h->D + 1) * h->ld));
@@ -2335,13 +2797,23 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
     TRY(dmalloc(&h->d_it_k, it_k.size())); TRY(dmalloc(&h->d_it_l, it_l.size())); TRY(dmalloc(&h->d_it_a, it_a.size()));
     TRY(dmalloc(&h->d_units, units.size())); TRY(dmalloc(&h->d_unit_ptr, P1));
-    TRY(dmalloc(&h->d_q_ptr, 9)); TRY(dmalloc(&h->d_q_units, q_units.size())); TRY(dmalloc(&h->d_q_head, 8));
+    TRY(dmalloc(&h->d_q_ptr, 9)); TRY(dmalloc(&h->d_q_units, q_units.size())); TRY(dmalloc(&h->d_q_head, 64));
+    TRY(dmalloc(&h->d_wdesc, wdesc.size())); TRY(dmalloc(&h->d_wunits, wunits.size()));
+#ifdef MVBA_SLOT_TRACE
+    if (getenv("MVBA_SLOT_TRACE")) { TRY(dmalloc(&h->d_trace, 8 * std::max<size_t>(1, wdesc.size()))); TRYH(hipMemset(h->d_trace, 0, 64 * std::max<size_t>(1, wdesc.size()))); }
+#endif
+    TRY(dmalloc(&h->d_seg_end, seg_end.size())); TRY(dmalloc(&h->d_prog, (size_t)h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
+    if (!seg_end.empty()) TRYH(hipMemcpy(h->d_seg_end, seg_end.data(), sizeof(int) * seg_end.size(), hipMemcpyHostToDevice));
+    if (!wdesc.empty()) {
+      TRYH(hipMemcpy(h->d_wdesc, wdesc.data(), sizeof(int4) * wdesc.size(), hipMemcpyHostToDevice));
+      TRYH(hipMemcpy(h->d_wunits, wunits.data(), sizeof(int) * wunits.size(), hipMemcpyHostToDevice));
+    }
     TRY(dmalloc(&h->d_partial, (size_t)UNIT_STRIDE * units.size()));
     if (!it_k.empty()) {
       TRYH(hipMemcpy(h->d_it_k, it_k.data(), sizeof(int) * it_k.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_l, it_l.data(), sizeof(int) * it_l.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_a, it_a.data(), sizeof(int) * it_a.size(), hipMemcpyHostToDevice));
-      {
+      if (h->schur_mode == SCHUR_PAIRS) {
         std::vector<int4> qdesc(units.size());  // descriptors in queue order (the kernel indexes both arrays by queue position)
         for (size_t i = 0; i < q_units.size(); ++i) qdesc[i] = units[q_units[i]];
         TRYH(hipMemcpy(h->d_units, qdesc.data(), sizeof(int4) * qdesc.size(), hipMemcpyHostToDevice));
@@ -2349,11 +2821,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         for (int x = 0; x < 8; ++x) mx = std::max(mx, q_ptr[x + 1] - q_ptr[x]);
         h->q_max = mx;
       }
-      TRYH(hipMemcpy(h->d_q_units, q_units.data(), sizeof(int) * q_units.size(), hipMemcpyHostToDevice));
+      if (!q_units.empty()) TRYH(hipMemcpy(h->d_q_units, q_units.data(), sizeof(int) * q_units.size(), hipMemcpyHostToDevice));
     }
     TRYH(hipMemcpy(h->d_unit_ptr, unit_ptr.data(), sizeof(int) * P1, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_q_ptr, q_ptr.data(), sizeof(int) * 9, hipMemcpyHostToDevice));
-    TRYH(hipMemset(h->d_q_head, 0, sizeof(int) * 8));
+    TRYH(hipMemset(h->d_q_head, 0, sizeof(int) * 64));
     TRYH(hipMemset(h->d_partial, 0, sizeof(double) * UNIT_STRIDE * std::max<size_t>(units.size(), 1)));
   }
   // opt in to large dynamic LDS
@@ -2388,11 +2860,27 @@ void mvba_destroy(mvba_handle *h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+#ifdef MVBA_SLOT_TRACE
+  if (h->d_trace && getenv("MVBA_SLOT_TRACE")) {
+    std::vector<long long> tr(8 * (size_t)h->n_waves);
+    hipMemcpy(tr.data(), h->d_trace, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost);
+    if (FILE *f = fopen(getenv("MVBA_SLOT_TRACE"), "w")) {
+      fprintf(f, "# block t0 t1 wait blocked polls hwid xcc nsteps (100 MHz ticks); nR=%d lag=%d nseg=%d\n", h->slot_nR, h->slot_lag, h->slot_nseg);
+      for (int b = 0; b < h->n_waves; ++b) {
+        fprintf(f, "%d", b);
+        for (int q = 0; q < 8; ++q) fprintf(f, " %lld", tr[8 * (size_t)b + q]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   if (h->comm) g_rccl.CommDestroy(h->comm);
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
-                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar};
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
+                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace};
   for (void *q : ptrs) if (q) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_allcost) hipHostFree(h->h_allcost);
@@ -2501,14 +2989,20 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const long long nAb = (long long)(nA + n9);
     const unsigned grid = (unsigned)std::max<long long>((h->N + 255) / 256, std::min<long long>((nAb + 1023) / 1024, 4096));
     hipLaunchKernelGGL(k_point_inv, dim3(std::max(grid, 1u)), dim3(256), 0, h->stream, h->N, c, h->d_PL, h->d_PB, h->d_flag,
-                       h->d_Ab, nAb);
+                       h->d_Ab, nAb, h->d_prog, h->slot_pace ? h->slot_nR * h->slot_nseg * PACE_STRIDE : 0);
   }
   if (h->use_pairs) {
     Timed t(h, MVBA_K_SCHUR);
-    if (h->n_units) {
-      static const bool stat = !getenv("MVBA_PAIR_STATIC") || atoi(getenv("MVBA_PAIR_STATIC"));  // experiment knob
-      // 64-bit offsets only when the records or the point blocks span 4 GiB (MVBA_FORCE_BIG: at test sizes too)
-      const bool big = std::max<long long>(h->nobs, h->N) * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");
+    // 64-bit offsets only when the records or the point blocks (+ the padding row) span 4 GiB (MVBA_FORCE_BIG: at test sizes too)
+    const bool big = (std::max<long long>(h->nobs, h->N) + 1) * 128LL >= (1LL << 32) || h->force_big;
+    if (h->schur_mode == SCHUR_SLOTS) {
+      if (h->n_waves)
+        hipLaunchKernelGGL(k_schur_slots, dim3(h->n_waves), dim3(64), SLOT_LDS, h->stream, h->d_wdesc,
+                           h->d_wunits, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial,
+                           h->pair_static ? nullptr : h->d_q_head, h->slot_nR, h->n_waves / std::max(1, h->slot_nR), h->d_seg_end,
+                           h->slot_pace ? h->d_prog : nullptr, h->slot_nseg, h->slot_lag, h->d_trace);
+    } else if (h->n_units) {
+      const bool stat = h->pair_static;
       hipLaunchKernelGGL(big ? k_schur_pairs_big : k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
                          2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k,
                          h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
@@ -2518,7 +3012,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   } else if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);
-    const bool big = h->nobs * 128LL >= (1LL << 32) || getenv("MVBA_FORCE_BIG");  // env: exercise the 64-bit-offset kernels at test sizes
+    const bool big = h->nobs * 128LL >= (1LL << 32) || h->force_big;  // (MVBA_FORCE_BIG: exercise the 64-bit-offset kernels at test sizes)
     auto kern = h->nsp ? (big ? k_schur_strip<true, true> : k_schur_strip<false, true>)
                        : (big ? k_schur_strip<true, false> : k_schur_strip<false, false>);
     hipLaunchKernelGGL(kern, dim3(m, h->nchunks, h->nseg), dim3(h->schur_threads), lds, h->stream, m, h->nchunks, h->lseg, h->nsp,
@@ -2579,7 +3073,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
                        h->d_cam15[trial]);
     if (h->N) {
       const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
-      static const int lanes_env = getenv("MVBA_BACKSUB_LANES") ? atoi(getenv("MVBA_BACKSUB_LANES")) : 0;  // experiment knob
+      const int lanes_env = h->backsub_lanes;  // (MVBA_BACKSUB_LANES at create; 0 = by mean degree)
       const double deg = (double)h->nobs / (double)h->N;
       const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
       const int nblk = (int)std::min<long long>(4096, (h->N * G + 255) / 256);
@@ -2659,11 +3153,11 @@ int mvba_get_info(mvba_handle *h, int64_t *out8) {
   out8[0] = h->n_items;
   out8[1] = h->n_items_offdiag;
   out8[2] = h->n_units;
-  out8[3] = h->use_pairs ? 1 : 0;
+  out8[3] = h->schur_mode;
   out8[4] = h->rccl_version;
   out8[5] = NCCL_VERSION_CODE;
   out8[6] = h->nranks;
-  out8[7] = 0;
+  out8[7] = h->schur_mode == SCHUR_SLOTS ? h->n_slot_items : 0;  // step-major rows incl. padding
   return MVBA_OK;
 }
 

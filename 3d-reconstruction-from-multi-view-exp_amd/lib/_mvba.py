@@ -204,7 +204,8 @@ class HipEngine:
 
     def schur_info(self):
         i = self._info()
-        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": "pairs" if i[3] else "strip"}
+        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": ("strip", "pairs", "slots")[i[3]],
+                "slot_rows": i[7]}  # slot form: step-major rows incl. the padding rows of the bounded-skew merge
 
     def rccl_version(self):
         i = self._info()

@@ -394,14 +394,16 @@ def main():
         info = eng.schur_info()
         k3_bytes = 192 * sc.n_obs
         k3_ach = k3_bytes / (k3_ms * 1e-3) / 1e9
-        k3_traffic, k3_src = pmc_traffic("k_schur_pairs", sc.n_obs)
+        k3_name = {"strip": "k_schur_strip", "pairs": "k_schur_pairs", "slots": "k_schur_slots"}[info["kernel"]]
+        k3_traffic, k3_src = pmc_traffic(k3_name, sc.n_obs)
         gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
         flops = info["items"] * 3 * 96 * 2
-        roof_k3 = {"kernel": "k_schur_pairs (K3)", "bound": "hbm", "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof_k3 = {"kernel": k3_name + " (K3)", "bound": "hbm", "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,
                    "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
                    "algorithmic_bytes_per_launch": k3_bytes, "algorithmic_bytes_per_obs": 192, "avg_launch_ms": k3_ms,
                    "items": info["items"], "units": info["units"],
+                   "slot_rows_incl_padding": info["slot_rows"] or None,
                    "gathered_bytes_per_launch": gather, "gather_GBs": gather / (k3_ms * 1e-3) / 1e9,
                    "fp64_tflops": flops / (k3_ms * 1e-3) / 1e12,
                    "frac_of_fp64_valu_peak": flops / (k3_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}

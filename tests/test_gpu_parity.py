@@ -405,15 +405,21 @@ def test_dense_solve_variants_agree(n, m, p, monkeypatch):
     np.testing.assert_allclose(got["launches"], got["default"], rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("n,m,p", [(3000, 14, 0.5), (900, 300, 0.06)])
-def test_strip_schur_kernels_match_the_oracle(n, m, p, monkeypatch):
-    """The camera-strip Schur kernel (round 1's K3, kept behind MVBA_SCHUR=strip as an independent
-    second implementation) in its 64-bit-offset form (MVBA_FORCE_BIG), plain and column-segmented."""
-    monkeypatch.setenv("MVBA_FORCE_BIG", "1")
-    monkeypatch.setenv("MVBA_SCHUR", "strip")
+@pytest.mark.parametrize("n,m,p,form", [(3000, 14, 0.5, "strip"), (900, 300, 0.06, "strip"), (3000, 14, 0.5, "pairs"),
+                                         (3000, 14, 0.5, "slots"), (20000, 60, 0.15, "slots"), (20000, 60, 0.15, "pairs")])
+def test_every_schur_kernel_form_matches_the_oracle(n, m, p, form, monkeypatch):
+    """The three forms of K3 -- the camera-strip kernel (round 1, plain and column-segmented), the
+    pair-major unit kernel (round 2: what runs beyond ~100 cameras) and the slot-resident kernel
+    (round 3: the default up to ~100 cameras) -- each forced with MVBA_SCHUR, the first two in their
+    64-bit-offset build (MVBA_FORCE_BIG; the slot form has none: scenes whose records span 4 GiB run
+    the unit form), against the oracle's reduced system."""
+    if form != "slots":
+        monkeypatch.setenv("MVBA_FORCE_BIG", "1")
+    monkeypatch.setenv("MVBA_SCHUR", form)
     sc = make_scene(n, m, vis_p=p)
     ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                           sc.init_R, sc.init_t, axis=sc.axis)
+    assert ba._engine.schur_info()["kernel"] == form
     g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
     g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
