@@ -186,3 +186,30 @@ def test_bench_self_launch_command_and_forwarding(monkeypatch, capsys):
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=3, stdout="boom\n"))
     assert bench.self_launch(["--gpus", "2"], 2) == 3
     assert capsys.readouterr().out == ""
+
+
+def test_slot_kernel_loops_carry_no_vector_memory_operation_the_counted_waits_do_not_know():
+    """k_schur_slots keeps two gathers in flight with COUNTED `s_waitcnt vmcnt(N)`: every vector-memory
+    operation of its loops is inline assembly, N is their number per iteration.  A register spill inside
+    a loop would add scratch accesses the count does not include (the 64-bit-offset build did exactly
+    that, and its results were wrong).  Checked on the generated ISA: between the first and the last
+    counted wait of the kernel there is no scratch / buffer access, and per iteration exactly the
+    operations the count assumes."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "3d-reconstruction-from-multi-view-exp_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
+    text = open(os.path.join(csrc, "mvba.s")).read()
+    m = re.search(r"^_ZN\d+_GLOBAL__N_113k_schur_slotsE\w*:[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    assert m, "k_schur_slots not found in the ISA"
+    lines = [ln.strip() for ln in m.group(1).splitlines()]
+    for count, n_ops in (("vmcnt(12)", 12), ("vmcnt(14)", 14)):  # diagonal / off-diagonal loop
+        idx = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt " + count)]
+        assert len(idx) == 2, (count, idx)  # the loop is unrolled by two
+        body = lines[idx[0]:idx[1]]
+        assert not any(ln.startswith(("scratch_", "buffer_")) for ln in body), [ln for ln in body if ln.startswith(("scratch_", "buffer_"))]
+        # one iteration = the gathers + the index loads, nothing else on the straight path (the pacing
+        # block's poll and arrival sit behind a branch that is not taken between segment boundaries)
+        straight = [ln for ln in body if ln.startswith(("global_load_lds_dwordx4", "global_load_dword "))]
+        straight = [ln for ln in straight if "sc1" not in ln]
+        assert len(straight) == n_ops, (count, len(straight))
