@@ -2204,6 +2204,9 @@ struct mvba_handle {
   std::vector<double> host_buf;
   int rank = 0, nranks = 1;
   double *d_allcost = nullptr, *h_allcost = nullptr, *d_sim = nullptr;
+  // debug log (mvba_snapshot): committed states kept in device memory, SNAP_SLAB entries per allocation
+  std::vector<double *> snap_slabs;
+  long long n_snap = 0;
   // profiling
   bool profiling = false;
   mvba_stats stats{};
@@ -2882,6 +2885,7 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
                   h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace};
   for (void *q : ptrs) if (q) hipFree(q);
+  for (double *q : h->snap_slabs) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
   if (h->h_allcost) hipHostFree(h->h_allcost);
   for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -3130,6 +3134,63 @@ int mvba_commit(mvba_handle *h) {
   h->cur = 1 - h->cur;
   h->have_trial = false; h->linearized = false;
   h->stats.n_commit++;
+  return MVBA_OK;
+}
+
+// ---- debug log: per-iteration copies of the committed state, device-resident (ref :89-98, :175-183, :204-206)
+namespace {
+constexpr int SNAP_SLAB = 8;  // log entries per device allocation
+size_t snap_stride(const mvba_handle *h) { return (3 * (size_t)h->N + (size_t)CAM_IN * h->m + 1) & ~(size_t)1; }
+}  // namespace
+
+int mvba_snapshot(mvba_handle *h) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t stride = snap_stride(h);
+  const size_t slab = (size_t)(h->n_snap / SNAP_SLAB);
+  if (slab >= h->snap_slabs.size()) {
+    double *p = nullptr;
+    int rc = dmalloc(&p, stride * SNAP_SLAB);
+    if (rc) return rc;
+    h->snap_slabs.push_back(p);
+  }
+  double *dst = h->snap_slabs[slab] + stride * (size_t)(h->n_snap % SNAP_SLAB);
+  // same stream as the kernels: ordered after everything that wrote the committed state and before whatever
+  // overwrites it; the host does not wait
+  MVBA_HIP(hipMemcpyAsync(dst, h->d_X[h->cur], sizeof(double) * 3 * h->N, hipMemcpyDeviceToDevice, h->stream));
+  MVBA_HIP(hipMemcpyAsync(dst + 3 * h->N, h->d_cam15[h->cur], sizeof(double) * CAM_IN * h->m, hipMemcpyDeviceToDevice, h->stream));
+  h->n_snap++;
+  return MVBA_OK;
+}
+
+int mvba_snapshot_count(mvba_handle *h, int64_t *n) {
+  if (!h || !n) return fail(MVBA_ERR_BADARG, "null argument");
+  *n = h->n_snap;
+  return MVBA_OK;
+}
+
+int mvba_snapshot_read(mvba_handle *h, int64_t i, double *X, double *f, double *u, double *t, double *R) {
+  if (!h || !X || !f || !u || !t || !R) return fail(MVBA_ERR_BADARG, "null argument");
+  if (i < 0 || i >= h->n_snap) return fail(MVBA_ERR_BADARG, "no such log entry");
+  MVBA_HIP(hipSetDevice(h->device));
+  const double *src = h->snap_slabs[(size_t)(i / SNAP_SLAB)] + snap_stride(h) * (size_t)(i % SNAP_SLAB);
+  std::vector<double> cam((size_t)h->m * CAM_IN);
+  MVBA_HIP(hipMemcpyAsync(X, src, sizeof(double) * 3 * h->N, hipMemcpyDeviceToHost, h->stream));
+  MVBA_HIP(hipMemcpyAsync(cam.data(), src + 3 * h->N, sizeof(double) * cam.size(), hipMemcpyDeviceToHost, h->stream));
+  MVBA_HIP(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < h->m; ++k) {
+    const double *c = cam.data() + (size_t)k * CAM_IN;
+    f[k] = c[0]; u[2 * k] = c[1]; u[2 * k + 1] = c[2];
+    for (int q = 0; q < 3; ++q) t[3 * k + q] = c[3 + q];
+    for (int q = 0; q < 9; ++q) R[9 * k + q] = c[6 + q];
+  }
+  return MVBA_OK;
+}
+
+int mvba_snapshot_clear(mvba_handle *h) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  h->n_snap = 0;  // (the slabs stay for the next run; mvba_destroy frees them)
   return MVBA_OK;
 }
 

@@ -47,6 +47,10 @@ SIGNATURES = {
     "mvba_set_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "mvba_get_params": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "mvba_apply_similarity": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double]),
+    "mvba_snapshot": (C.c_int, [C.c_void_p]),
+    "mvba_snapshot_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mvba_snapshot_read": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp]),
+    "mvba_snapshot_clear": (C.c_int, [C.c_void_p]),
     "mvba_cost": (C.c_int, [C.c_void_p, _dp]),
     "mvba_linearize": (C.c_int, [C.c_void_p]),
     "mvba_try_step": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -158,6 +162,24 @@ class HipEngine:
         t = np.empty((self.m, 3)); R = np.empty((self.m, 3, 3))
         raise_for(self.lib.mvba_get_params(self._h, _ptr(X), _ptr(f), _ptr(u), _ptr(t), _ptr(R)), self.lib)
         return X, f, u, t, R
+
+    # -- debug log (ref :89-98, :175-183): copies of the committed state kept on the device
+    def snapshot(self):
+        raise_for(self.lib.mvba_snapshot(self._h), self.lib)
+
+    def snapshot_count(self):
+        n = C.c_int64()
+        raise_for(self.lib.mvba_snapshot_count(self._h, C.byref(n)), self.lib)
+        return n.value
+
+    def snapshot_read(self, i):
+        X = np.empty((self.n, 3)); f = np.empty(self.m); u = np.empty((self.m, 2))
+        t = np.empty((self.m, 3)); R = np.empty((self.m, 3, 3))
+        raise_for(self.lib.mvba_snapshot_read(self._h, int(i), _ptr(X), _ptr(f), _ptr(u), _ptr(t), _ptr(R)), self.lib)
+        return X, f, u, t, R
+
+    def snapshot_clear(self):
+        raise_for(self.lib.mvba_snapshot_clear(self._h), self.lib)
 
     def apply_similarity(self, R0, t0, scale):
         """Committed state -> scale * X R0^T + t0 (likewise t), R0 R, on the device (ref :242-258)."""

@@ -175,11 +175,19 @@ class BundleAdjuster:
     ) -> tuple[npt.NDArray, npt.NDArray, npt.NDArray, npt.NDArray]:
         on_state = None
         if is_debug:
-            self._log.clear()
+            self._log.clear()  # ref :90
+            self._log_errors = []
+            on_device = hasattr(self._engine, "snapshot")
+            if on_device:
+                self._engine.snapshot_clear()
 
             def on_state(err):  # log entries are copies, normalised frame (ref :91-97, :175-183)
-                X, _, _, t, R = self._engine.get_params()
-                self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": err})
+                if on_device:  # a device-to-device copy on the engine's stream; fetched by get_log()
+                    self._engine.snapshot()
+                    self._log_errors.append(err)
+                else:  # engines that keep their state on the host (the test oracle)
+                    X, _, _, t, R = self._engine.get_params()
+                    self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": err})
 
         lm_loop(self._engine, scale_factor, delta_tol, max_iter, on_state)
         # the reference rebinds its state to the de-normalised values (:198-200): the engine applies
@@ -195,4 +203,12 @@ class BundleAdjuster:
         return X, intrinsics_from(f, u, self._f0), R, t
 
     def get_log(self) -> list[dict[str, npt.NDArray | float]]:
+        """ref :204-206.  On the device path the per-iteration states were kept in device memory while
+        optimize() ran (`mvba_snapshot`); they cross PCIe here, once, the first time the log is asked for."""
+        pending = getattr(self, "_log_errors", None)
+        if pending:
+            for i in range(len(self._log), len(pending)):
+                X, _, _, t, R = self._engine.snapshot_read(i)
+                self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": pending[i]})
+            self._log_errors = []
         return self._log

@@ -101,6 +101,17 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial);
 /* trial -> committed (ref :169-173). */
 int mvba_commit(mvba_handle *h);
 
+/* The debug log of the reference's optimize(is_debug=True) (ref :89-98, :175-183: a copy of X, R, t per outer
+ * iteration, normalised frame; read back by get_log(), :204-206).  mvba_snapshot appends the COMMITTED state to
+ * a log kept in device memory -- one device-to-device copy on the engine's stream, nothing crosses PCIe and the
+ * host does not wait; mvba_snapshot_read fetches entry i (what get_log() does, once, afterwards);
+ * mvba_snapshot_clear empties the log (the reference clears it at the start of every optimize, :90) and keeps
+ * its memory for the next run. */
+int mvba_snapshot(mvba_handle *h);
+int mvba_snapshot_count(mvba_handle *h, int64_t *n);
+int mvba_snapshot_read(mvba_handle *h, int64_t i, double *X, double *f, double *u, double *t, double *R);
+int mvba_snapshot_clear(mvba_handle *h);
+
 /* Per-kernel device timing; off by default. */
 int mvba_set_profiling(mvba_handle *h, int32_t enabled);
 int mvba_get_stats(mvba_handle *h, mvba_stats *out);
@@ -108,9 +119,10 @@ int mvba_reset_stats(mvba_handle *h);
 
 /* Sizes of the Schur index built at create and what the communicator runs on (bench.py prices the
  * kernels with them): out[0] (point, camera pair) items incl. diagonal pairs, out[1] off-diagonal
- * items, out[2] units (wave runs), out[3] 1 = pair-major Schur kernel / 0 = strip kernel,
- * out[4] ncclGetVersion() of the librccl actually loaded (0 without a communicator), out[5] the
- * NCCL_VERSION_CODE the library was compiled against, out[6] ranks, out[7] reserved. */
+ * items, out[2] units (wave runs / slot lists), out[3] Schur kernel form: 0 = camera strips (round 1),
+ * 1 = pair-major units (round 2), 2 = slot-resident (round 3), out[4] ncclGetVersion() of the librccl
+ * actually loaded (0 without a communicator), out[5] the NCCL_VERSION_CODE the library was compiled
+ * against, out[6] ranks, out[7] slot form: step-major item rows including the padding rows. */
 int mvba_get_info(mvba_handle *h, int64_t *out8);
 
 /* Point-sharded multi-GPU (one process per GPU): rank 0 makes an id, the host

@@ -392,7 +392,33 @@ def calibration_vectors():
     _save("calibration", **out)
 
 
+def trajectory_logs():
+    """get_log() contents along the two default trajectories (ref :89-98, :175-183: copies of X, R, t in the
+    NORMALISED frame per outer iteration): the reference's BundleAdjuster is run again on the BA inputs
+    the fixtures above already hold, and a few log entries (first, two inside, last) are kept."""
+    out = {}
+    for name, picks in (("euclid_default", (0, 3, 17, -1)), ("affine_default", (0, 5, 50, -1)), ("visibility_300x12", (0, 4, -1))):
+        d = np.load(os.path.join(HERE, name + ".npz"), allow_pickle=False)
+        vis = d["vis"] if "vis" in d.files else None
+        args = {"euclid_default": (2.0, 1e-8, 100), "affine_default": (2.0, 1e-8, 100), "visibility_300x12": (2.0, -1.0, 10)}[name]
+        ba = BundleAdjuster(d["x"], d["init_X"], d["init_K"], d["init_R"], d["init_t"], visibility_index=vis, axis="x-up_z-forward")
+        _quiet(ba.optimize, args[0], args[1], max_iter=args[2], is_debug=True)
+        log = ba.get_log()
+        assert np.allclose([e["reprojection_error"] for e in log], d["E_log"], rtol=1e-12, atol=0)
+        out[name + "_len"] = np.int64(len(log))
+        out[name + "_picks"] = np.array([p % len(log) for p in picks])
+        for p in picks:
+            i = p % len(log)
+            out[f"{name}_{i}_points"], out[f"{name}_{i}_basis"], out[f"{name}_{i}_pos"] = log[i]["points"], log[i]["basis"], log[i]["pos"]
+            out[f"{name}_{i}_E"] = np.float64(log[i]["reprojection_error"])
+    _save("trajectory_logs", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. `make_golden.py trajectory_logs`: only the named vectors
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     euclid_default()
     affine_default()
     linearization_dump("linearize_60x7_xup", "x-up_z-forward", 11)
@@ -401,3 +427,4 @@ if __name__ == "__main__":
     factorization_vectors()
     small_known_answers()
     calibration_vectors()
+    trajectory_logs()  # (reads the BA inputs out of the fixtures written above)

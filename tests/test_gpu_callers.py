@@ -67,9 +67,45 @@ def test_perspective_self_calibration_gpu(golden, method, capsys):
         dist = lambda Y: np.linalg.norm(Y[:, None] - Y[None], axis=2)[iu]  # noqa: E731
         np.testing.assert_allclose(dist(X), dist(d["persp_dual_X"]), rtol=1e-5, atol=1e-7)
     else:
-        assert mine < 1.5 * ref + 1e-3, (mine, ref)
+        assert mine < 1.5 * ref + 1e-3, (mine, ref)  # (sanity only: the stages are pinned one by one below)
     with pytest.raises(ValueError):
         P.perspective_self_calibration(xs, method="bogus")
+
+
+@pytest.mark.parametrize("method", ["primary", "dual"])
+def test_perspective_self_calibration_stage_by_stage_on_the_gpu(golden, method, capsys):
+    """Every stage of perspective_self_calibration (ref perspective_camera_calibration.py:513-540) on the GPU
+    SVD against what the reference produced at that stage: converged depths (:61-144 / :147-235), the
+    factorization of the re-weighted matrix (:533), one turn of the Omega <-> K loop on it (:238-411).
+    The primary method's END result is chaotic on this scene (J = 1.9e9 after one turn: a 1e-15
+    difference is O(1) two turns later), which is why the stages, not the end, carry the parity."""
+    from lib.factorization import factorization_method
+
+    d = golden("calibration")
+    x = P._create_data_matrix([a.copy() for a in d["persp_x"]], 1.0)
+    fn = getattr(P, f"_compute_projective_depth_{method}_method")
+    z = fn(x, 1.0, 1e-2)
+    capsys.readouterr()
+    np.testing.assert_allclose(z, np.abs(d[f"persp_{method}_z"]), rtol=0, atol=1e-9)  # (per-image sign: see the CPU test)
+    # the reference's own depths (sign included) -> the GPU factorization == the reference's M, S
+    W = x * d[f"persp_{method}_z"][..., None]
+    M, S = factorization_method(W.reshape(W.shape[0], -1).T)
+    Mr, Sr = d[f"persp_{method}_M"], d[f"persp_{method}_S"]
+    sg = np.sign(np.sum(M * Mr, axis=0))
+    assert (np.abs(sg) == 1).all()
+    np.testing.assert_allclose(M * sg, Mr, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(S * sg[:, None], Sr, rtol=0, atol=1e-8 * np.abs(Sr).max())
+    np.testing.assert_allclose(M @ S, Mr @ Sr, rtol=0, atol=1e-9 * np.abs(Mr @ Sr).max())
+    # one turn of the upgrade loop on the GPU factors
+    Pm = (M * sg).reshape(-1, 3, 4)
+    K0 = np.tile(np.eye(3), (10, 1, 1))
+    Q0 = np.linalg.inv(K0) @ Pm
+    Om, sig, _w = P._calc_omega(Q0)
+    np.testing.assert_allclose(Om, d[f"persp_{method}_Omega1"], rtol=0, atol=1e-7 * np.abs(d[f"persp_{method}_Omega1"]).max())
+    np.testing.assert_allclose(sig, d[f"persp_{method}_sigma1"], rtol=1e-6, atol=1e-9)
+    K1, J1 = P._update_K(K0.copy(), Om, Q0)
+    np.testing.assert_allclose(K1, d[f"persp_{method}_K1"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(J1, d[f"persp_{method}_J1"], rtol=1e-5)
 
 
 def test_projective_depths_per_step_on_the_gpu_svd(golden, capsys):
@@ -114,9 +150,20 @@ def test_affine_driver_runs(golden, capsys):
     x_list, (X, K, R, t), log = drv.main(show=False)
     np.testing.assert_allclose(np.stack(x_list).transpose(1, 0, 2), d["x"], atol=1e-13)
     E = np.array([e["reprojection_error"] for e in log])
-    assert len(E) >= 2 and E[-1] < 0.05 * E[0]
-    # either the reference's minimum (0.2179) or the mirror-parity one (0.0993): SURVEY §7 hard part 4
-    assert min(abs(E[-1] - 0.21790752620130377), abs(E[-1] - 0.0993)) < 5e-3, E[-1]
+    # The reference's run: 100 outer iterations (max_iter) ending at E = 0.21790752620130377.  Which minimum BA
+    # reaches depends on the PARITY of the three singular-vector signs (an odd number of flips mirrors the
+    # affine reconstruction: BA then stops after 36 solves at 0.09933032816).  The repo's sign rule ("largest
+    # entry of each column of U positive") has LAPACK's parity on this scene, so the driver reproduces the
+    # reference's minimum -- tests/test_callers_cpu.py pins both minima on the oracle.
+    assert len(E) == len(d["E_log"]) == 101
+    assert E[-1] == pytest.approx(0.21790752620130377, rel=1e-6), E[-1]
+    assert E[0] == pytest.approx(float(d["E_log"][0]), rel=1e-6)
+    # and the opt-in mirror parity (lib.affine_camera_calibration._svd_on_gpu(..., mirror=True))
+    U3, S3, t3 = A._svd_on_gpu([x.copy() for x in x_list], mirror=True)
+    U3r, S3r, _ = A._svd_on_gpu([x.copy() for x in x_list])
+    np.testing.assert_allclose(U3[:, :2], U3r[:, :2], atol=0)
+    np.testing.assert_allclose(U3[:, 2], -U3r[:, 2], atol=0)
+    np.testing.assert_allclose(S3[2], -S3r[2], atol=0)
 
 
 def test_device_projection_matches_lib_camera(golden):

@@ -88,6 +88,13 @@ def test_product_lm_loop_over_oracle_engine(golden, name, args, capsys):
     if name == "euclid_default":
         np.testing.assert_allclose(log[0]["points"], d["log0_points"], atol=1e-12)
         np.testing.assert_allclose(log[-1]["basis"], d["logN_basis"], atol=1e-6)
+    tl = golden("trajectory_logs")  # the reference's own log entries (first, inside, last)
+    if name + "_len" in tl.files:
+        assert len(log) == int(tl[name + "_len"])
+        for i in tl[name + "_picks"]:
+            tol = 1e-9 if i < 10 else 1e-6
+            for key in ("points", "basis", "pos"):
+                np.testing.assert_allclose(log[i][key], tl[f"{name}_{i}_{key}"], rtol=0, atol=tol)
 
 
 def test_bad_axis_raises_value_error(golden):
