@@ -25,6 +25,8 @@
 // stream and the events resident across calls; mvsvd_factorize is the one-shot form.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -35,6 +37,8 @@ using namespace mvba;
 namespace {
 
 constexpr int GT = 16;             // Gram tile = one v_mfma_f64_16x16x4_f64 accumulator
+constexpr int GRAM_SLICES = 32;    // second level of the fixed-order Gram reduction
+constexpr int COLSUM_SLICES = 256;
 constexpr int ROWS_PER_STEP = 32;  // rows consumed per unrolled step (8 MFMA k-groups of 4 rows)
 typedef double svd_d4 __attribute__((ext_vector_type(4)));
 
@@ -60,28 +64,37 @@ __device__ __forceinline__ void gram_store_partial(const svd_d4 *acc, int npairs
   }
 }
 
-// n <= 16 * NT (NT = 1 or 2): one pass over the rows forms every tile pair (1 or 3 MFMAs per 4 rows).
+// n <= 32: one pass over the rows forms every tile pair.  MODE 1: n <= 16, one MFMA per 4 rows.  MODE 3: 24 < n <= 32,
+// the three tile pairs (0,0), (0,1), (1,1).  MODE 2: 16 < n <= 24 (config 5: 24 columns), TWO MFMAs: tile (0,0) and a
+// PACKED tile whose rows are columns 8..23 and whose columns are [16..23 | 0..7] -- it holds G[8..23][16..23] and
+// G[16..23][0..7], i.e. everything tile (0,0) lacks; the half-empty (0,1) and quarter-full (1,1) tiles of MODE 3 cost a
+// third more matrix-core time for the same 300 entries (the kernel is bound by the f64 MFMA issue rate).
 // A workgroup takes GRAM_ROWS consecutive rows per step: the rows are one contiguous byte range of
 // Wt, streamed with 16-byte loads by all 256 threads into LDS (a lane-per-element gather of the
 // MFMA operands straight from HBM ran at 1.8 TB/s), then every wave picks the operands of its
 // 32 rows out of LDS.  Rows past the end are zero-filled in LDS.
 constexpr int GRAM_ROWS = 4 * ROWS_PER_STEP;  // 128 rows per workgroup step
-template <typename T, int NT>
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, long long n_rows, int n,
                                                     const double *__restrict__ mu, double *__restrict__ partial) {
   extern __shared__ double gram_lds_raw[];
   T *stage = reinterpret_cast<T *>(gram_lds_raw);  // GRAM_ROWS x n, row-major like Wt
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  constexpr int NP = NT * (NT + 1) / 2;
+  constexpr int NP = MODE == 1 ? 1 : (MODE == 2 ? 2 : 3);  // MFMAs per 4 rows = partial tiles
+  constexpr int NC = MODE == 1 ? 1 : (MODE == 2 ? 3 : 2);  // operand columns a lane reads per row
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
   svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
-  int col[NT];
-  bool cok[NT];
-  double muc[NT];  // column mean to subtract (0 without centring)
+  int col[NC];
+  bool cok[NC];
+  double muc[NC];  // column mean to subtract (0 without centring)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { cok[t] = GT * t + li < n; col[t] = min(GT * t + li, n - 1); muc[t] = mu ? mu[col[t]] : 0.0; }
+  for (int t = 0; t < NC; ++t) {
+    // MODE 1/3: column 16 t + li.  MODE 2: li | 8 + li | (li < 8 ? 16 + li : li - 8)
+    const int c = MODE == 2 ? (t == 0 ? li : (t == 1 ? 8 + li : (li < 8 ? 16 + li : li - 8))) : GT * t + li;
+    cok[t] = c < n; col[t] = min(c, n - 1); muc[t] = mu ? mu[col[t]] : 0.0;
+  }
   const long long total = n_rows * n;
   const int nvec = GRAM_ROWS * n / VEC;  // GRAM_ROWS * n is a multiple of 4
   for (long long r0 = (long long)blockIdx.y * GRAM_ROWS; r0 < n_rows; r0 += (long long)gridDim.y * GRAM_ROWS) {
@@ -109,18 +122,23 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
     const long long row0 = r0 + wave * ROWS_PER_STEP + lk;
 #pragma unroll
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
-      double v[NT];
+      double v[NC];
       const bool rok = row0 + 4 * g < n_rows;  // rows past the end are zeros in LDS: keep them zero when centring
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NC; ++t) {
         const double x = (double)rows[(size_t)(4 * g) * n + col[t]] - muc[t];
         v[t] = (cok[t] && rok) ? x : 0.0;
       }
-      int q = 0;
+      if (MODE == 2) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0], v[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[1], v[2], acc[1], 0, 0, 0);
+      } else {
+        int q = 0;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NC; ++t)
 #pragma unroll
-        for (int u = t; u < NT; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t], v[u], acc[q], 0, 0, 0);
+          for (int u = t; u < NC; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t], v[u], acc[q], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -157,19 +175,50 @@ __global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, lon
   gram_store_partial(acc, 1, blockIdx.x, n_pairs, partial);
 }
 
-// G[gi][gj] = sum over row chunks of the partial tiles (fixed order: deterministic)
-__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int chunks, int n, int n_tiles,
-                                                     int n_pairs, double *__restrict__ G) {
-  int ti = 0, pr = blockIdx.x;
-  while (pr >= n_tiles - ti) { pr -= n_tiles - ti; ++ti; }
-  const int tj = ti + pr;
-  const int e = threadIdx.x, r = (e >> 6) & 3, l = e & 63;
+// Two fixed-order levels instead of atomics: k_gram_reduce sums a slice of the row chunks per block
+// (slice s of tile pair p -> part2[s][p][256]), k_gram_finish adds the slices in order and writes the full symmetric G.
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ partial, int chunks, int n_pairs,
+                                                     double *__restrict__ part2) {
+  const int e = threadIdx.x;
   double sacc = 0.0;  // gridDim.y slices of the chunk range, 8 independent loads in flight
   const int c0 = (int)((long long)chunks * blockIdx.y / gridDim.y), c1 = (int)((long long)chunks * (blockIdx.y + 1) / gridDim.y);
 #pragma unroll 8
   for (int c = c0; c < c1; ++c) sacc += partial[((size_t)c * n_pairs + blockIdx.x) * 256 + e];
-  const int gi = GT * ti + (l >> 4) + 4 * r, gj = GT * tj + (l & 15);
-  if (gi < n && gj < n) atomicAdd(&G[(size_t)gi * n + gj], sacc);
+  part2[((size_t)blockIdx.y * n_pairs + blockIdx.x) * 256 + e] = sacc;
+}
+
+// element (row, col) of a 16 x 16 MFMA C/D tile as gram_store_partial lays it out: col = l & 15, row = (l >> 4) + 4 reg
+__device__ __forceinline__ int tile_elem(int row, int col) { return ((row >> 2) << 6) | ((row & 3) << 4) | col; }
+
+// G[i][j] = G[j][i] = sum over the slices (in order) of the tile entry that holds it.  `packed`: the two-tile layout
+// of k_gram_fused MODE 2.  Entries a layout holds twice (both halves of a diagonal tile) are averaged.
+__global__ void k_gram_finish(const double *__restrict__ part2, int slices, int n_pairs, int n_tiles, int packed,
+                              double *__restrict__ G, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n || j < i) return;
+  auto fetch = [&](int pair, int elem) {  // (every load issued before the first add: one memory latency, not `slices`)
+    double t[GRAM_SLICES];
+#pragma unroll
+    for (int s = 0; s < GRAM_SLICES; ++s) t[s] = part2[((size_t)min(s, slices - 1) * n_pairs + pair) * 256 + elem];
+    double v = 0.0;
+#pragma unroll
+    for (int s = 0; s < GRAM_SLICES; ++s) v += s < slices ? t[s] : 0.0;
+    return v;
+  };
+  double v;
+  if (packed) {
+    if (j < 16) v = (i == j) ? fetch(0, tile_elem(i, j)) : 0.5 * (fetch(0, tile_elem(i, j)) + fetch(0, tile_elem(j, i)));
+    else if (i < 8) v = fetch(1, tile_elem(j - 8, 8 + i));                      // G[j][i], j >= 16 > 8 > i
+    else if (i < 16) v = fetch(1, tile_elem(i - 8, j - 16));                    // G[i][j], 8 <= i < 16 <= j
+    else v = (i == j) ? fetch(1, tile_elem(i - 8, j - 16)) : 0.5 * (fetch(1, tile_elem(i - 8, j - 16)) + fetch(1, tile_elem(j - 8, i - 16)));
+  } else {
+    const int ti = i / GT, tj = j / GT;
+    const int pair = ti * n_tiles - ti * (ti - 1) / 2 + (tj - ti);
+    v = fetch(pair, tile_elem(i - GT * ti, j - GT * tj));
+    if (ti == tj && j > i) v = 0.5 * (v + fetch(pair, tile_elem(j - GT * tj, i - GT * ti)));  // diagonal tiles hold both halves
+  }
+  G[(size_t)i * n + j] = v;
+  G[(size_t)j * n + i] = v;
 }
 
 // column sums (only when centring is requested): one block row per column, grid-stride over rows
@@ -187,12 +236,15 @@ __global__ __launch_bounds__(256) void k_colsum(const T *__restrict__ Wt, long l
     if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(&colsum[c], red[0]);
+  if (threadIdx.x == 0) colsum[(size_t)blockIdx.y * n + c] = red[0];  // one partial per (slice, column): no atomics
 }
 
-__global__ void k_mean_from_sum(const double *__restrict__ colsum, int n, long long n_rows, double *__restrict__ mu) {
+__global__ void k_mean_from_sum(const double *__restrict__ colsum, int slices, int n, long long n_rows, double *__restrict__ mu) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n) mu[c] = colsum[c] / (double)n_rows;
+  if (c >= n) return;
+  double s = 0.0;
+  for (int q = 0; q < slices; ++q) s += colsum[(size_t)q * n + c];  // fixed order
+  mu[c] = s / (double)n_rows;
 }
 
 // B[row][j] = sum_c (Wt[row][c] - mu[c]) V[c][j]   (fp64 out): the preconditioning rotation of the
@@ -246,16 +298,6 @@ __global__ __launch_bounds__(256) void k_rotate(const T *__restrict__ Wt, long l
   }
 }
 
-// G (upper tiles) -> full symmetric
-__global__ void k_gram_finish(double *__restrict__ G, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-  if (j >= n || j < i) return;
-  double v = G[(size_t)i * n + j];
-  if (i / GT == j / GT && j > i) v = 0.5 * (v + G[(size_t)j * n + i]);  // diagonal tiles hold both halves
-  G[(size_t)i * n + j] = v;
-  G[(size_t)j * n + i] = v;
-}
-
 // Round-robin parallel Jacobi on the symmetric n x n matrix A (global memory), eigenvectors in V.
 // np = n rounded up to even (a phantom index np-1 == n is skipped).
 template <bool IN_LDS>  // IN_LDS: both n x n matrices live in LDS (n <= 64): latency ~100 ns instead of ~1.5 us
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ Ag, double
             const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
             c = 1.0 / sqrt(1.0 + t * t);
             s = t * c;
-            atomicAdd(&s_off, 1.0);
+            s_off = 1.0;  // (a flag: every writer stores the same value)
           }
         }
         pp[i] = p; qq[i] = q; rc[i] = c; rs[i] = s;
@@ -488,6 +530,73 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
   }
 }
 
+// ---- depth-weighted matrix from a resident base (mvsvd_run_scaled): W[a][j] = X[a][j] z[a][j / group] s,
+// s = 1 / |row a of X o z| (norm 1: every row to unit length, ref perspective_camera_calibration.py:86-87) or
+// s = 1 / sum over rows and the group's columns of (X o z)^2 (norm 2: every column group -- image -- divided by its
+// SQUARED Frobenius norm, ref :170-172).  One thread per row; the group sums of norm 2 are per-block partials added in
+// fixed order (k_group_scale).
+template <typename T>
+__global__ __launch_bounds__(256) void k_group_sumsq(const T *__restrict__ X, const T *__restrict__ z, long long n_rows, int n,
+                                                     int group, double *__restrict__ part /*[gridDim.x][n / group]*/) {
+  const int ng = n / group;
+  // thread t of the block owns group t % ng of the rows t / ng, t / ng + rows_per_pass, ...: every group's partial is
+  // accumulated by a fixed set of threads in a fixed order, then summed over those threads in thread order
+  const int rows_per_pass = blockDim.x / ng;
+  const int g = threadIdx.x % ng, rloc = threadIdx.x / ng;
+  double acc = 0.0;
+  if (rloc < rows_per_pass)
+    for (long long a = (long long)blockIdx.x * rows_per_pass + rloc; a < n_rows; a += (long long)gridDim.x * rows_per_pass) {
+      const double zz = (double)z[a * ng + g];
+      for (int c = 0; c < group; ++c) {
+        const double w = (double)X[a * n + g * group + c] * zz;
+        acc += w * w;
+      }
+    }
+  __shared__ double s_acc[256];
+  s_acc[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < ng) {
+    double t = 0.0;
+    for (int r = 0; r < rows_per_pass; ++r) t += s_acc[r * ng + threadIdx.x];
+    part[(size_t)blockIdx.x * ng + threadIdx.x] = t;
+  }
+}
+
+__global__ void k_group_scale(const double *__restrict__ part, int blocks, int ng, double *__restrict__ cs) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  double t = 0.0;
+  for (int b = 0; b < blocks; ++b) t += part[(size_t)b * ng + g];
+  cs[g] = 1.0 / t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_rows(const T *__restrict__ X, const T *__restrict__ z, long long n_rows, int n,
+                                                    int group, int norm, const double *__restrict__ cs, T *__restrict__ W) {
+  const int ng = n / group;
+  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
+    const T *xr = X + a * n;
+    const T *zr = z + a * ng;
+    T *wr = W + a * n;
+    double rs = 1.0;
+    if (norm == 1) {
+      double ss = 0.0;
+      for (int g = 0; g < ng; ++g) {
+        const double zz = (double)zr[g];
+        for (int c = 0; c < group; ++c) {
+          const double w = (double)xr[g * group + c] * zz;
+          ss += w * w;
+        }
+      }
+      rs = 1.0 / sqrt(ss);
+    }
+    for (int g = 0; g < ng; ++g) {
+      const double f = (double)zr[g] * (norm == 2 ? cs[g] : rs);
+      for (int c = 0; c < group; ++c) wr[g * group + c] = (T)((double)xr[g * group + c] * f);
+    }
+  }
+}
+
 }  // namespace
 
 // Workspace: the resident matrix and every buffer a factorisation needs, allocated once.
@@ -497,8 +606,11 @@ struct mvsvd_handle {
   hipStream_t st = nullptr;
   hipEvent_t ev[6] = {};
   void *dW = nullptr, *dS = nullptr;
-  double *dG = nullptr, *dV = nullptr, *dV1 = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr, *dB = nullptr;
+  double *dG = nullptr, *dV = nullptr, *dV1 = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr, *dpart2 = nullptr, *dB = nullptr;
   int *dsw = nullptr;
+  void *dX = nullptr, *dz = nullptr;  // mvsvd_load_base / mvsvd_run_scaled: resident base matrix, the depths of one call
+  double *dgs = nullptr;              // column-group partial sums and scales
+  bool base_loaded = false;
   int chunks = 1, rank_cap = 0;
   double h2d_ms = 0.0;
   bool loaded = false;
@@ -508,16 +620,20 @@ namespace {
 
 template <typename T>
 void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) {
-  const int n = h->n, n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
-  hipMemsetAsync(h->dG, 0, sizeof(double) * (size_t)n * n, h->st);
-  if (n_tiles == 1)
+  const int n = h->n, n_tiles = (n + GT - 1) / GT;
+  const bool packed = n > 16 && n <= 24;
+  const int n_pairs = packed ? 2 : n_tiles * (n_tiles + 1) / 2;
+  if (n <= 16)
     hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
-  else if (n_tiles == 2)
+  else if (packed)
     hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
+  else if (n <= 32)
+    hipLaunchKernelGGL((k_gram_fused<T, 3>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
   else
     hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, h->st, W, h->n_rows, n, n_tiles, n_pairs, mu, h->dpart);
-  hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, std::min(chunks, 32)), dim3(256), 0, h->st, h->dpart, chunks, n, n_tiles, n_pairs, h->dG);
-  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dG, n);
+  const int slices = std::min(chunks, GRAM_SLICES);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, slices), dim3(256), 0, h->st, h->dpart, chunks, n_pairs, h->dpart2);
+  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dpart2, slices, n_pairs, n_tiles, packed ? 1 : 0, h->dG, n);
 }
 
 // tol: rotate while |a_pq| > tol sqrt(|a_pp a_qq|).  1e-15 for float64 input; float32 input carries
@@ -551,10 +667,9 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
   hipEventRecord(h->ev[1], st);
   const double *mu = nullptr;
   if (center) {  // column means first: the rows are centred as they enter the products
-    MVBA_HIP(hipMemsetAsync(h->dsum, 0, sizeof(double) * n, st));
-    const int cy = (int)std::max<long long>(1, std::min<long long>(256, n_rows / 4096));
+    const int cy = (int)std::max<long long>(1, std::min<long long>(COLSUM_SLICES, n_rows / 4096));
     hipLaunchKernelGGL(k_colsum<T>, dim3(n, cy), dim3(256), 0, st, dW, n_rows, n, h->dsum);
-    hipLaunchKernelGGL(k_mean_from_sum, dim3((n + 255) / 256), dim3(256), 0, st, h->dsum, n, n_rows, h->dmu);
+    hipLaunchKernelGGL(k_mean_from_sum, dim3((n + 255) / 256), dim3(256), 0, st, h->dsum, cy, n, n_rows, h->dmu);
     mu = h->dmu;
   }
   launch_gram<T>(h, dW, mu, chunks);
@@ -657,10 +772,11 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipMalloc((void **)&h->dV, sizeof(double) * nn));
   SVD_TRY(hipMalloc((void **)&h->dV1, sizeof(double) * nn));
   SVD_TRY(hipMalloc((void **)&h->dMr, sizeof(double) * std::max(nn, (size_t)4 * n_cols)));
-  SVD_TRY(hipMalloc((void **)&h->dsum, sizeof(double) * n_cols));
+  SVD_TRY(hipMalloc((void **)&h->dsum, sizeof(double) * n_cols * COLSUM_SLICES));
   SVD_TRY(hipMalloc((void **)&h->dmu, sizeof(double) * n_cols));
   SVD_TRY(hipMalloc((void **)&h->dsw, sizeof(int)));
   SVD_TRY(hipMalloc((void **)&h->dpart, sizeof(double) * (size_t)h->chunks * n_pairs * 256));
+  SVD_TRY(hipMalloc((void **)&h->dpart2, sizeof(double) * (size_t)GRAM_SLICES * n_pairs * 256));
   SVD_TRY(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -674,7 +790,7 @@ void mvsvd_destroy(mvsvd_handle *h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
   for (void *p : {h->dW, h->dS, (void *)h->dG, (void *)h->dV, (void *)h->dV1, (void *)h->dsum, (void *)h->dMr, (void *)h->dmu,
-                  (void *)h->dsw, (void *)h->dpart, (void *)h->dB})
+                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs})
     if (p) hipFree(p);
   for (auto &e : h->ev)
     if (e) hipEventDestroy(e);
@@ -705,6 +821,62 @@ int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *si
   MVBA_HIP(hipSetDevice(h->device));
   if (h->dtype == 0) return run<float>(h, n_rank, center, (float *)M, (float *)sigma, (float *)S, (float *)means, timings_ms);
   return run<double>(h, n_rank, center, (double *)M, (double *)sigma, (double *)S, (double *)means, timings_ms);
+}
+
+int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows) {
+  if (!h || !X) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_rows < 1 || n_rows > h->max_rows) return fail(MVBA_ERR_BADARG, "n_rows outside the workspace (1 .. max_rows)");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t el = h->dtype ? 8 : 4;
+  if (!h->dX) MVBA_HIP(hipMalloc(&h->dX, el * (size_t)h->max_rows * h->n));
+  MVBA_HIP(hipMemcpyAsync(h->dX, X, el * (size_t)n_rows * h->n, hipMemcpyHostToDevice, h->st));
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  h->n_rows = n_rows;
+  h->base_loaded = true;
+  h->loaded = false;  // dW holds nothing derived from this base yet
+  return MVBA_OK;
+}
+
+int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
+                     double *timings_ms) {
+  if (!h || !z || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->base_loaded) return fail(MVBA_ERR_STATE, "mvsvd_run_scaled before mvsvd_load_base");
+  if (group < 1 || h->n % group) return fail(MVBA_ERR_BADARG, "group must divide n_cols");
+  if (norm < 0 || norm > 2) return fail(MVBA_ERR_BADARG, "norm must be 0 (none), 1 (unit rows) or 2 (column groups by their squared norm)");
+  if (n_rank < 1 || n_rank > h->n) return fail(MVBA_ERR_BADARG, "need 1 <= n_rank <= n_cols");
+  const int ng = h->n / group;
+  if (ng > 256) return fail(MVBA_ERR_BADARG, "at most 256 column groups");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t el = h->dtype ? 8 : 4;
+  constexpr int GS_BLOCKS = 512;
+  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
+  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
+  hipEventRecord(h->ev[0], h->st);
+  MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->n_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
+  hipEventRecord(h->ev[1], h->st);
+  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
+  const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->n_rows + 255) / 256));
+  const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->n_rows / 64 + 1));
+  if (h->dtype == 0) {
+    if (norm == 2) {
+      hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->n_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+    }
+    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->n_rows, h->n, group, norm, cs, (float *)h->dW);
+  } else {
+    if (norm == 2) {
+      hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->n_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+    }
+    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->n_rows, h->n, group, norm, cs, (double *)h->dW);
+  }
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+  h->h2d_ms = ms;
+  h->loaded = true;
+  if (h->dtype == 0) return run<float>(h, n_rank, 0, (float *)M, (float *)sigma, (float *)S, (float *)nullptr, timings_ms);
+  return run<double>(h, n_rank, 0, (double *)M, (double *)sigma, (double *)S, (double *)nullptr, timings_ms);
 }
 
 int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank, int32_t center, void *M,

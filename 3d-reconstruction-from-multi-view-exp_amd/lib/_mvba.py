@@ -71,6 +71,8 @@ SIGNATURES = {
     "mvsvd_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "mvsvd_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mvsvd_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
+    "mvsvd_load_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mvsvd_run_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
     "mvsvd_destroy": (None, [C.c_void_p]),
 }
 
@@ -326,6 +328,30 @@ class SvdWorkspace:
         raise_for(self.lib.mvsvd_load(self._h, Wt.ctypes.data, Wt.shape[0]), self.lib)
         self.n_rows = Wt.shape[0]
         return self
+
+    def load_base(self, X):
+        """The resident base matrix of run_scaled (one upload for a whole depth loop)."""
+        X = np.ascontiguousarray(X, dtype=self.dtype)
+        if X.ndim != 2 or X.shape[1] != self.n_cols:
+            raise ValueError("X must be (n_rows, n_cols) of the workspace")
+        raise_for(self.lib.mvsvd_load_base(self._h, X.ctypes.data, X.shape[0]), self.lib)
+        self.n_rows = X.shape[0]
+        return self
+
+    def run_scaled(self, z, group, norm, n_rank):
+        """Factorise X o z (depths z (n_rows, n_cols / group) per column group, normalised: norm 1 = unit rows,
+        2 = column groups by their squared norm) from the resident base: only z is uploaded.
+        M (n_cols, r), sigma (n_cols,), S (r, n_rows), timings."""
+        z = np.ascontiguousarray(z, dtype=self.dtype)
+        if z.shape != (self.n_rows, self.n_cols // int(group)):
+            raise ValueError("z must be (n_rows, n_cols / group)")
+        M = np.empty((self.n_cols, n_rank), self.dtype)
+        sigma = np.empty(self.n_cols, self.dtype)
+        S = np.empty((n_rank, self.n_rows), self.dtype)
+        tm = np.zeros(6)
+        raise_for(self.lib.mvsvd_run_scaled(self._h, z.ctypes.data, int(group), int(norm), int(n_rank), M.ctypes.data,
+                                            sigma.ctypes.data, S.ctypes.data, _ptr(tm)), self.lib)
+        return M, sigma, S, _tm(tm)
 
     def run(self, n_rank, center=False):
         """M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings."""

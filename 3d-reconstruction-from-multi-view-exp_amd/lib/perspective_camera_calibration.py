@@ -33,6 +33,7 @@ class _GpuSvd4:
 
     def __init__(self):
         self._ws = None
+        self._base = None
 
     def __call__(self, Wt: npt.NDArray):
         from ._mvba import SvdWorkspace
@@ -45,10 +46,28 @@ class _GpuSvd4:
         M, sigma, S, _mu, _tm = self._ws.load(Wt).run(4)
         return M, sigma, S
 
+    def scaled(self, x: npt.NDArray, z: npt.NDArray, norm: int):
+        """The depth loops' factorisation of x o z (x (N, m, 3) homogeneous observations, z (N, m) depths), normalised
+        (norm 1: every point's 3m-vector to unit length, ref :86-87; norm 2: every image's block by its squared
+        Frobenius norm, ref :170-172): x is uploaded ONCE per loop (`mvsvd_load_base`), afterwards only z crosses
+        PCIe and the re-weighted matrix is formed on the device (`mvsvd_run_scaled`)."""
+        from ._mvba import SvdWorkspace
+
+        n, m = x.shape[:2]
+        if self._ws is None or self._base is not x:
+            if self._ws is not None:
+                self._ws.close()
+            self._ws = SvdWorkspace(n, 3 * m, np.float64)
+            self._ws.load_base(x.reshape(n, 3 * m))
+            self._base = x
+        M, sigma, S, _tm = self._ws.run_scaled(z, 3, norm, 4)
+        return M, sigma, S
+
     def close(self):
         if self._ws is not None:
             self._ws.close()
             self._ws = None
+            self._base = None
 
 
 def _gpu_svd4(Wt: npt.NDArray):
@@ -91,9 +110,12 @@ def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 2
     count = 0
     svd = svd or _GpuSvd4()
     while True:
-        W = x * z[..., None]
-        W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]  # every point's 3m-column to unit length
-        M, _sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
+        if hasattr(svd, "scaled"):  # device path: x stays resident, z is all that is uploaded
+            M, _sigma, S = svd.scaled(x, z, 1)
+        else:
+            W = x * z[..., None]
+            W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]  # every point's 3m-column to unit length
+            M, _sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
         U4 = M.reshape(n_images, 3, 4)
         # C[a, k, i] = (x_ak . u_ik) / |x_ak|;  A_a = C_a C_a^T is the reference's m x m matrix (:99-107)
         C = np.einsum("akc,kci->aki", x, U4) / x_norm[..., None]
@@ -119,10 +141,13 @@ def _compute_projective_depth_dual_method(x, f0, tolerance, max_iter: int = 50, 
     count = 0
     svd = svd or _GpuSvd4()
     while True:
-        W = x * z[..., None]
-        # each image's 3 x N block divided by its SQUARED Frobenius norm (:170-172)
-        W = W / (W**2).sum(axis=(0, 2))[None, :, None]
-        M, sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
+        if hasattr(svd, "scaled"):  # device path: x stays resident, z is all that is uploaded
+            M, sigma, S = svd.scaled(x, z, 2)
+        else:
+            W = x * z[..., None]
+            # each image's 3 x N block divided by its SQUARED Frobenius norm (:170-172)
+            W = W / (W**2).sum(axis=(0, 2))[None, :, None]
+            M, sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
         if not (sigma[:4] > 0).all():           # rank-deficient measurement matrix: no 4th right singular vector
             raise np.linalg.LinAlgError("measurement matrix has rank < 4")
         V4 = (S / sigma[:4, None]).T             # (N, 4) right singular vectors

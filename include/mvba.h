@@ -203,6 +203,17 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
 int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows);
 int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *sigma, void *S, void *means,
               double *timings_ms);
+
+/* The projective-depth loops (ref perspective_camera_calibration.py:61-144, :147-235) factorise, 50-200 times,
+ * the SAME homogeneous observations X re-weighted by the current depths: W[a][g*group + c] = X[a][g*group + c] *
+ * z[a][g] * s with s = 1 / |row a of X o z| (norm 1: every row -- point -- to unit length, ref :86-87), s = 1 / sum of
+ * the group's (X o z)^2 over all rows (norm 2: every column group -- image -- divided by its squared Frobenius
+ * norm, ref :170-172) or s = 1 (norm 0).  mvsvd_load_base uploads X (n_rows x n_cols, the workspace's dtype) once;
+ * every mvsvd_run_scaled uploads only z (n_rows x n_cols / group), forms W on the device and runs the factorisation
+ * (no centring).  timings_ms[0] is then the upload of z. */
+int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows);
+int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
+                     double *timings_ms);
 void mvsvd_destroy(mvsvd_handle *h);
 
 #ifdef __cplusplus

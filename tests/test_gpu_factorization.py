@@ -2,11 +2,15 @@
 with the reference's factorization_method outputs (tests/golden/factorization_24x2000.npz,
 euclid_default.npz: fact_W/M/S captured from the reference).  Singular vectors are defined up to
 sign, so sign-invariant quantities are compared: sigma, the product M @ S and |M^T M_ref|."""
+import os
+
 import numpy as np
 import pytest
 
 from lib import _mvba
 from lib.factorization import factorization_method
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -205,3 +209,64 @@ def test_any_rank_and_workspace_reuse(dtype):
 def test_bad_arguments():
     with pytest.raises(ValueError):
         _mvba.svd_factorize(np.zeros((10, 4)), 5)
+
+
+@pytest.mark.parametrize("dtype,norm", [(np.float64, 1), (np.float64, 2), (np.float32, 1), (np.float64, 0)])
+def test_depth_weighted_factorisation_from_a_resident_base(dtype, norm):
+    """mvsvd_load_base + mvsvd_run_scaled (the projective-depth loops, ref perspective_camera_calibration.py
+    :81-87 and :170-179: W = x o z, rows to unit length / image blocks by their squared norm, SVD, 50-200 times):
+    the base matrix is uploaded once, every call uploads the depths only and forms W on the device.  Equal to
+    loading the host-formed W: the same kernels run on the same numbers (the scaling itself rounds once in the
+    matrix dtype on both sides, in a different order of operations: a few ulp)."""
+    rng = np.random.default_rng(11)
+    n, m = 40_000, 8
+    x = np.concatenate([rng.normal(size=(n, m, 2)), np.ones((n, m, 1))], axis=2)
+    z = 1.0 + 0.2 * rng.uniform(size=(n, m))
+    W = x * z[..., None]
+    if norm == 1:
+        W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]
+    elif norm == 2:
+        W = W / (W**2).sum(axis=(0, 2))[None, :, None]
+    Wt = np.ascontiguousarray(W.reshape(n, 3 * m)).astype(dtype)
+    ws = _mvba.SvdWorkspace(n, 3 * m, dtype)
+    M0, s0, S0, _mu, _ = ws.load(Wt).run(4)
+    ws.load_base(x.reshape(n, 3 * m).astype(dtype))
+    M1, s1, S1, tm = ws.run_scaled(z.astype(dtype), 3, norm, 4)
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    np.testing.assert_allclose(s1[:4].astype(np.float64), s0[:4].astype(np.float64), rtol=tol)
+    sg = np.sign(np.sum(M0.astype(np.float64) * M1.astype(np.float64), axis=0))
+    np.testing.assert_allclose(M1 * sg, M0, rtol=0, atol=10 * tol)
+    np.testing.assert_allclose(S1 * sg[:, None], S0, rtol=0, atol=10 * tol * np.abs(S0).max())
+    # and against LAPACK on the host-formed matrix
+    s_ref = np.linalg.svd(Wt.astype(np.float64), compute_uv=False)
+    np.testing.assert_allclose(s1[:4].astype(np.float64), s_ref[:4], rtol=1e-5 if dtype == np.float32 else 1e-9)
+    # a second call with other depths on the same base: nothing but z is uploaded again
+    z2 = z * (1.0 + 0.1 * rng.uniform(size=z.shape))
+    M2, s2, S2, _ = ws.run_scaled(z2.astype(dtype), 3, norm, 4)
+    assert not np.allclose(s2[:4], s1[:4], rtol=1e-6) or norm == 1
+    with pytest.raises(ValueError):
+        ws.run_scaled(z[:, :3], 3, norm, 4)
+    ws.close()
+
+
+def test_depth_loop_uploads_the_depths_only_at_5m_rows():
+    """What mvsvd_run_scaled is for, at config 5's row count: per depth iteration 5M x 8 depths (160 MB fp32)
+    cross PCIe instead of the 5M x 24 matrix (480 MB)."""
+    rng = np.random.default_rng(0)
+    n, m = 5_000_000, 8
+    x = rng.standard_normal((n, 3 * m), dtype=np.float32)
+    z = (1.0 + 0.1 * rng.random((n, m), dtype=np.float32)).astype(np.float32)
+    ws = _mvba.SvdWorkspace(n, 3 * m, np.float32)
+    ws.load_base(x)
+    M, s, S, tm = ws.run_scaled(z, 3, 1, 4)
+    M, s, S, tm = ws.run_scaled(z, 3, 1, 4)
+    W = (x.reshape(n, m, 3) * z[..., None]).reshape(n, 3 * m)
+    W /= np.linalg.norm(W, axis=1, keepdims=True)
+    _, _, _, _, tm_full = ws.load(W).run(4)
+    ws.close()
+    # rows of unit length: sum of sigma^2 = n
+    assert abs(float((s.astype(np.float64) ** 2).sum()) / n - 1.0) < 1e-4
+    with open(os.path.join(ROOT, "gpurun_out", "r03_svd_scaled_5m.txt"), "w") as fh:
+        fh.write(f"5,000,000 x 24 fp32 depth iteration: upload of z {tm['h2d_ms']:.2f} ms (160 MB) vs upload of W {tm_full['h2d_ms']:.2f} ms (480 MB); "
+                 f"device: gram {tm['gram_ms']:.3f} jacobi {tm['jacobi_ms']:.3f} project {tm['project_ms']:.3f} ms\n")
+    assert tm["h2d_ms"] < 0.6 * tm_full["h2d_ms"]
