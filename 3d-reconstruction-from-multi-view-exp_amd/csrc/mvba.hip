@@ -140,6 +140,17 @@ __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
   return (i + 6 < 12 + gauge_axis) ? i + 6 : i + 7;
 }
 
+// Wave-uniform operands are read through the constant address space so that the compiler issues scalar (SMEM)
+// loads into SGPRs instead of 64 identical vector loads.
+#define MVBA_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const T MVBA_CONST_AS *)p;
+#pragma clang diagnostic pop
+}
+
 // ------------------------------------------------------------------ K1
 // One thread per observation, grid-stride over 256-observation tiles; camera table
 // staged once per block.  Each wave transposes its 64 records through LDS so that
@@ -150,13 +161,14 @@ __device__ __forceinline__ int keep_index(int i, int gauge_axis) {
 // Algorithmic traffic: 24 B in + 128 B out per observation + (24 in + 72 out) B per point.
 constexpr int REC = 8;  // double2 slots per observation record (128 B)
 
-__global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
+__global__ __launch_bounds__(512, 4) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
                                                    const double *__restrict__ X,
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
                                                    const double2 *__restrict__ xy, double f0,
                                                    const int *__restrict__ tile_start, int n_tiles,
-                                                   double2 *__restrict__ rec, double *__restrict__ PL) {
+                                                   double2 *__restrict__ rec, double *__restrict__ PL,
+                                                   const int *__restrict__ tile_slot, double *__restrict__ PLsplit) {
   extern __shared__ double smem[];
   double *s_cam = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -172,10 +184,12 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
   // Wave tiles are POINT-ALIGNED (built once on the host): whole points packed greedily into at
   // most 64 observations, so every per-point sum below is complete inside one wave -> plain
   // stores, no atomics, bitwise-reproducible E_a / dP_a.  Only a point with more than 64
-  // observations is split over tiles (tile_start < 0 marks such a tile; its sums are added).
+  // observations is split over tiles (tile_start < 0 marks such a tile: it holds ONE piece of ONE point, whose sums
+  // go to slot tile_slot[tile] of a side buffer; k_sum_split adds a point's pieces in tile order afterwards).
   for (int tile = blockIdx.x * nwave + wave; tile < n_tiles; tile += gridDim.x * nwave) {
     const int ts0 = tile_start[tile], ts1 = tile_start[tile + 1];
     const bool split = ts0 < 0;
+    const int slot = split ? as_const(tile_slot)[tile] : 0;  // (wave-uniform: a scalar load)
     const long long wbase = split ? ~ts0 : ts0;  // first observation of this wave's tile
     const int n = (int)((ts1 < 0 ? ~ts1 : ts1) - wbase);
     const long long o = wbase + lane;
@@ -240,13 +254,24 @@ __global__ __launch_bounds__(512) void k_resid_jac(long long nobs, int m, const 
         const int i0 = seg_start[sg], i1 = seg_start[sg + 1];
         double acc = 0.0;
         for (int i = i0; i < i1; ++i) acc += contrib[comp * CS + i];
-        double *dst = &PL[9 * (size_t)seg_pt[sg] + comp];
-        if (split) atomicAdd(dst, acc);  // piece of a > 64-observation point: PL was zero-filled
-        else *dst = acc;
+        // (split: a piece of a > 64-observation point -> its slot of the side buffer; wave-uniform choice)
+        if (split) PLsplit[9 * (size_t)slot + comp] = acc;
+        else PL[9 * (size_t)seg_pt[sg] + comp] = acc;
       }
     }
     wave_sync();
   }
+}
+
+// The per-point blocks of points with more than 64 observations: their pieces in tile order (fixed order: no atomics).
+__global__ void k_sum_split(int n_split, const int4 *__restrict__ splits /* point, first slot, pieces */,
+                            const double *__restrict__ PLsplit, double *__restrict__ PL) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, sp = t / 9, comp = t - 9 * sp;
+  if (sp >= n_split) return;
+  const int4 d = splits[sp];
+  double v = 0.0;
+  for (int q = 0; q < d.z; ++q) v += PLsplit[9 * (size_t)(d.y + q) + comp];
+  PL[9 * (size_t)d.x + comp] = v;
 }
 
 // ------------------------------------------------------------------ K3a
@@ -311,14 +336,6 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
 // and the right-hand side 2 Jc_k^T (Jx_k v_a - e_ak)   (ref :138-143, :471-517).
 // Wave-uniform operands are read through the constant address space so the
 // compiler issues scalar (SMEM) loads into SGPRs instead of 64 identical vector loads.
-#define MVBA_CONST_AS __attribute__((address_space(4)))
-template <typename T>
-__device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-  return (const T MVBA_CONST_AS *)p;
-#pragma clang diagnostic pop
-}
 
 // LDS strip layout: strip[(9 (l - l_lo) + j) * 9 + i]  (i fastest) so that the nine
 // accumulations of a lane are ONE address + immediate offsets; sb (rhs) follows.
@@ -480,13 +497,13 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
       // ---------------- the 9 accumulations of pass n (asynchronous from here on)
       if (valid) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(dst + i, val[i]);
+        for (int i = 0; i < 9; ++i) unsafeAtomicAdd(dst + i, val[i]);  // ds_add_f64 (this kernel IS its LDS atomics)
       }
       if (done) break;
     }
     if (seg == 0 && lane < 9) {
-      atomicAdd(strip + lane * 9 + lane, dacc);  // (1+c) damping of G_k's diagonal (ref :123-125)
-      atomicAdd(&sb[lane], bacc);
+      unsafeAtomicAdd(strip + lane * 9 + lane, dacc);  // (1+c) damping of G_k's diagonal (ref :123-125)
+      unsafeAtomicAdd(&sb[lane], bacc);
     }
   }
   __syncthreads();
@@ -495,9 +512,9 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
   for (int q = threadIdx.x; q < 9 * W; q += blockDim.x) {
     const int row = q / W, col = q - row * W;  // coalesced over the columns of A
     const double val = strip[col * 9 + row];
-    if (val != 0.0) atomicAdd(&Ak[(size_t)row * Wk + col], val);
+    if (val != 0.0) unsafeAtomicAdd(&Ak[(size_t)row * Wk + col], val);
   }
-  if (seg == 0 && threadIdx.x < 9) atomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
+  if (seg == 0 && threadIdx.x < 9) unsafeAtomicAdd(&bfull[9 * k + threadIdx.x], sb[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ K3 (pair-major form)
@@ -2156,6 +2173,10 @@ struct mvba_handle {
   double2 *d_xy = nullptr;
   int4 *d_csc = nullptr;
   int *d_tiles = nullptr;  // K1 point-aligned wave tiles
+  int *d_tile_slot = nullptr;      // points with more than 64 observations: slot of every piece tile in d_PLsplit,
+  int4 *d_splits = nullptr;        // (point, first slot, pieces) per such point
+  double *d_PLsplit = nullptr;
+  int n_splits = 0;
   int n_tiles = 0;
   bool any_split = false;
   long long *d_chunk_ptr = nullptr;
@@ -2379,7 +2400,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
 
   // K1 wave tiles: whole points packed greedily into <= 64 observations; a point with more than
   // 64 observations is cut into pieces whose tiles are flagged by a complemented (negative) start
-  std::vector<int> tiles;
+  std::vector<int> tiles, tile_slot;
+  std::vector<int4> splits;
+  int n_split_slots = 0;
   bool any_split = false;
   {
     long long cur0 = 0, fill = 0;
@@ -2389,7 +2412,13 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       if (d > 64) {
         if (fill) { flush(false); cur0 += fill; fill = 0; }
         any_split = true;
-        for (long long q = 0; q < d; q += 64) { flush(true); cur0 += std::min<long long>(64, d - q); }
+        splits.push_back(make_int4((int)a, n_split_slots, (int)((d + 63) / 64), 0));
+        for (long long q = 0; q < d; q += 64) {
+          tile_slot.resize(tiles.size() + 1, -1);
+          tile_slot[tiles.size()] = n_split_slots++;
+          flush(true);
+          cur0 += std::min<long long>(64, d - q);
+        }
         continue;
       }
       if (fill + d > 64) { flush(false); cur0 += fill; fill = 0; }
@@ -2763,6 +2792,15 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_csc, nobs));
   h->n_tiles = (int)tiles.size() - 1;
   h->any_split = any_split;
+  if (any_split) {
+    tile_slot.resize(tiles.size(), -1);
+    h->n_splits = (int)splits.size();
+    TRY(dmalloc(&h->d_tile_slot, tile_slot.size()));
+    TRY(dmalloc(&h->d_splits, splits.size()));
+    TRY(dmalloc(&h->d_PLsplit, 9 * (size_t)n_split_slots));
+    TRYH(hipMemcpy(h->d_tile_slot, tile_slot.data(), sizeof(int) * tile_slot.size(), hipMemcpyHostToDevice));
+    TRYH(hipMemcpy(h->d_splits, splits.data(), sizeof(int4) * splits.size(), hipMemcpyHostToDevice));
+  }
   TRY(dmalloc(&h->d_tiles, tiles.size()));
   TRY(dmalloc(&h->d_chunk_ptr, chunk_ptr.size()));
   for (int i = 0; i < 2; ++i) { TRY(dmalloc(&h->d_X[i], 3 * N)); TRY(dmalloc(&h->d_cam15[i], (size_t)CAM_IN * m)); }
@@ -2879,7 +2917,7 @@ void mvba_destroy(mvba_handle *h) {
   }
 #endif
   if (h->comm) g_rccl.CommDestroy(h->comm);
-  void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
+  void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_tile_slot, h->d_splits, h->d_PLsplit, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
@@ -2963,8 +3001,6 @@ int mvba_linearize(mvba_handle *h) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   if (!h->have_params) return fail(MVBA_ERR_STATE, "no parameters set");
   MVBA_HIP(hipSetDevice(h->device));
-  if (h->any_split)  // only pieces of > 64-observation points are accumulated with atomics
-    MVBA_HIP(hipMemsetAsync(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(h->N, 1), h->stream));
   if (h->nobs) {
     Timed t(h, MVBA_K_RESID_JAC);  // K1 with K2 (per-point blocks) fused in
     const int kt = h->k1_threads;  // 8 waves share one camera table: 2 blocks = 16 waves per CU
@@ -2972,7 +3008,11 @@ int mvba_linearize(mvba_handle *h) {
     const int wpb = kt / 64;
     const int grid = std::max(1, std::min(2048 * 256 / kt, (h->n_tiles + wpb - 1) / wpb));
     hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(kt), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
-                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_tiles, h->n_tiles, h->d_rec, h->d_PL);
+                       h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_tiles, h->n_tiles, h->d_rec, h->d_PL,
+                       h->d_tile_slot, h->d_PLsplit);
+    if (h->n_splits)
+      hipLaunchKernelGGL(k_sum_split, dim3((9 * h->n_splits + 255) / 256), dim3(256), 0, h->stream, h->n_splits, h->d_splits,
+                         h->d_PLsplit, h->d_PL);
   }
   MVBA_HIP(hipGetLastError());
   h->linearized = true; h->have_trial = false;

@@ -50,6 +50,19 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (f
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_config3.json")
 
 
+def csrc_sha256():
+    """sha256 over the kernel sources: the committed PMC figures are only quoted for the sources they were taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("csrc/mvba.hip", "csrc/mvba_common.h", "csrc/mvsvd.hip", "csrc/Makefile"):
+        with open(os.path.join(PKG, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(ROOT, "include", "mvba.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, n_obs):
     """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes of this workload
     (tools/final_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB; FETCH_SIZE doubled
@@ -60,6 +73,8 @@ def pmc_traffic(kernel, n_obs):
         k = d["kernels"][kernel]
         if int(d["n_obs"]) != int(n_obs):
             return None, None
+        if d.get("csrc_sha256") != csrc_sha256():  # the kernels have changed since the counters were collected
+            return None, f"profiles/pmc_config3.json @ {d.get('commit', '?')} is STALE (kernel sources changed since): traffic omitted"
         return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, f"profiles/pmc_config3.json @ {d.get('commit', '?')}"
     except Exception:  # noqa: BLE001
         return None, None

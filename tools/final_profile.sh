@@ -8,5 +8,12 @@ python tools/kstats.py gpurun_out/${tag}_kernel_stats.csv > gpurun_out/${tag}_ke
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1 || { tail -5 gpurun_out/pmc_${tag}_$name.log; exit 1; }; }
 run fetch FETCH_SIZE && run write WRITE_SIZE && run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum && run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_VALU && run sq2 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES && run grbm GRBM_GUI_ACTIVE
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_*/ > gpurun_out/${tag}_pmc_summary.txt
+python - > gpurun_out/${tag}_pmc_config3.json <<PY
+import json, subprocess, sys
+d = json.load(open("gpurun_out/prof_${tag}.json"))
+c = d["config"]
+print(subprocess.run([sys.executable, "tools/pmc_to_json.py", str(c["observations_total"]), str(c["points_total"]), "${tag}",
+                      "gpurun_out/pmc_${tag}_fetch", "gpurun_out/pmc_${tag}_write", "gpurun_out/pmc_${tag}_tcc"], capture_output=True, text=True, check=True).stdout)
+PY
 cat gpurun_out/${tag}_kernel_stats.txt | head -12
 grep -A3 "k_resid_jac" gpurun_out/${tag}_pmc_summary.txt | head -8
