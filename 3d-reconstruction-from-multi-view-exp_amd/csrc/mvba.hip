@@ -2375,6 +2375,15 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     return fail(MVBA_ERR_BADARG, "n_obs and n_points per handle must be < 2^31");
   const long long N = p->n_points, nobs = p->n_obs;
   const int m = p->n_images;
+  // MVBA_CREATE_TIMING=1: phase times of this call on stderr (a diagnostic, read once here)
+  const bool timing = getenv("MVBA_CREATE_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "mvba_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // validate + build point-of-observation and the camera-major index
   std::vector<int> obs_pt(nobs);
   std::vector<long long> csc_ptr(m + 1, 0);
@@ -2390,14 +2399,18 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     }
   }
   for (int k = 0; k < m; ++k) csc_ptr[k + 1] += csc_ptr[k];
-  std::vector<int4> csc(nobs);
-  {
+  // the camera-major index belongs to the strip kernel alone (round 1's K3: MVBA_SCHUR=strip, or more cameras than a
+  // pair id holds): 160 MB at config 3 that the other forms never read
+  const bool want_strip = (getenv("MVBA_SCHUR") && !strcmp(getenv("MVBA_SCHUR"), "strip")) || m > 65535;
+  std::vector<int4> csc(want_strip ? nobs : 0);
+  if (want_strip) {
     std::vector<long long> fill(csc_ptr.begin(), csc_ptr.end() - 1);
     for (long long a = 0; a < N; ++a)
       for (long long o = p->pt_ptr[a]; o < p->pt_ptr[a + 1]; ++o)
         csc[fill[p->cam_idx[o]]++] = make_int4((int)o, (int)a, (int)(p->pt_ptr[a + 1] - o), 0);
   }
 
+  lap("validate, obs_pt, csc");
   // K1 wave tiles: whole points packed greedily into <= 64 observations; a point with more than
   // 64 observations is cut into pieces whose tiles are flagged by a complemented (negative) start
   std::vector<int> tiles, tile_slot;
@@ -2428,6 +2441,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     tiles.push_back((int)nobs);  // terminator (never negative: only its magnitude is used)
   }
 
+  lap("K1 tiles");
   mvba_handle *h = new mvba_handle();
   if (p->device >= 0) {
     hipError_t e = hipSetDevice(p->device);
@@ -2454,7 +2468,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (const char *ev = getenv("MVBA_SCHUR_LSEG")) h->lseg = std::max(1, std::min(h->lseg, atoi(ev)));
   h->nseg = (m + h->lseg - 1) / h->lseg;
   h->nsp = (h->nseg >= 2 && h->nseg <= 4 && m < 1024) ? h->nseg : 0;
-  if (h->nsp) {  // segment boundaries inside each entry's remaining (camera-sorted) observations
+  if (h->nsp && want_strip) {  // segment boundaries inside each entry's remaining (camera-sorted) observations
     for (long long e = 0; e < nobs; ++e) {
       const int *cb = p->cam_idx + csc[e].x, *ce = cb + csc[e].z;
       int w = 0;
@@ -2463,8 +2477,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       csc[e].w = w;
     }
   }
-  std::vector<long long> chunk_ptr((size_t)m * (h->nchunks + 1));
-  for (int k = 0; k < m; ++k) {
+  std::vector<long long> chunk_ptr(want_strip ? (size_t)m * (h->nchunks + 1) : 0);
+  for (int k = 0; k < m && want_strip; ++k) {
     const int4 *b = csc.data() + csc_ptr[k], *e = csc.data() + csc_ptr[k + 1];
     for (int c = 0; c <= h->nchunks; ++c) {
       const long long a_lo = (long long)((__int128)N * c / h->nchunks);
@@ -2473,6 +2487,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     }
   }
 
+  lap("strip chunk index");
   // ---- pair-major Schur index (see k_schur_pairs).  Items (obs of k, obs of l, point) for every
   // pair k <= l of a point's cameras, counting-sorted by pair, ascending point inside a pair.
   if (const char *ev = getenv("MVBA_SCHUR"))
@@ -2513,6 +2528,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
       }
     });
+    lap("pair counts");
     long long T = 0, Tdiag = 0;
     for (int k = 0; k < m; ++k) Tdiag += cnt[pair_id(k, k)];
     for (long long q = 0; q < P; ++q) T += cnt[q];
@@ -2593,6 +2609,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
       });
     }
+    lap("items sorted by pair");
     // units: (pair, sub-list, point range), numbered pair-major (k_schur_reduce sums them in this order)
     unit_ptr.assign(P + 1, 0);
     std::vector<int> uid((size_t)VP * nR, -1);
@@ -2612,6 +2629,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
       }
     unit_ptr[P] = (int)units.size();
+    lap("units");
     if (slots) {
       // ---- waves of 21 lists (off-diagonal lists first, then the diagonal pairs' sub-lists), every wave once per range
       std::vector<int> lists_off, lists_diag;  // list ids v = vp_ptr[pair] + sub-list
@@ -2705,6 +2723,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       on_threads([&](int tid) {
         for (long long b = tid; b < n_waves; b += n_thr) merge(b, 0, false);
       });
+      lap("slot merge (count)");
       for (long long b = 0; b < n_waves; ++b)
         for (int j = 0; j < nWin; ++j) {
           int &mx = win_max[(size_t)(b % nR) * nWin + j];
@@ -2727,6 +2746,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         for (long long b = tid; b < n_waves; b += n_thr)
           if (w_steps[b]) merge(b, w_beg[b], true);
       });
+      lap("slot merge (fill)");
       const int w_off_ = w_off;
       std::vector<int> live(nR, 0);  // waves of a range that run at all: what a pacing counter has to reach
       for (long long b = 0; b < n_waves; ++b) live[b % nR] += w_steps[b] > 0;
@@ -2779,6 +2799,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     h->n_items_offdiag = T - Tdiag;
     h->n_units = (int)units.size();
   }
+  lap("queues / wave descriptors");
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
   h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks
 
@@ -2789,7 +2810,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_cam, nobs));
   TRY(dmalloc(&h->d_obs_pt, nobs));
   TRY(dmalloc(&h->d_xy, nobs));
-  TRY(dmalloc(&h->d_csc, nobs));
+  TRY(dmalloc(&h->d_csc, csc.size()));
   h->n_tiles = (int)tiles.size() - 1;
   h->any_split = any_split;
   if (any_split) {
@@ -2827,12 +2848,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_obs_pt, obs_pt.data(), sizeof(int) * nobs, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
-    TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
+    if (want_strip) TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
   }
   TRYH(hipMemcpy(h->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
   // points without observations are never written by K1: their blocks stay zero (-> singular, ref :128)
   TRYH(hipMemset(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(N, 1)));
-  TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
+  if (want_strip) TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   if (h->use_pairs) {
     const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
@@ -2893,6 +2914,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
 #undef TRY
 #undef TRYH
+  lap("device allocations + uploads");
   *out = h;
   return MVBA_OK;
 }
