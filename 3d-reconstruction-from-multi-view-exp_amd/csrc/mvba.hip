@@ -2157,6 +2157,153 @@ __global__ __launch_bounds__(256) void k_similarity(long long npts, int m, doubl
   }
 }
 
+// ------------------------------------------------------------------ Schur index on the device (mvba_create)
+// The slot form's index -- every (point, camera pair) item, counting-sorted by pair with ascending points inside a
+// pair, dealt into sub-lists, then merged wave by wave into step-major rows -- built by kernels instead of 16 host
+// threads (0.7 s of a 0.83 s mvba_create at config 3).  A STABLE counting sort: wave w owns a contiguous chunk of
+// points and walks them in order, its lanes taking the items of one (point, first camera) row at a time -- distinct
+// pairs, so the wave's private histogram in LDS needs no atomics and an item's rank inside its pair is
+// [items of earlier waves] + [items of this wave so far]: exactly the position the host's sequential pass gives it.
+constexpr int IDX_WAVES = 4;  // waves per block of the counting / filling kernels (one P-int histogram each in LDS)
+
+__device__ __forceinline__ int idx_pair_id(int k, int l, int m) { return k * m - k * (k - 1) / 2 + (l - k); }
+
+// hist[w][q] = items of pair q among the points of wave w's chunk
+__global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_count(long long N, int m, int P, const long long *__restrict__ pt_ptr,
+                                                              const int *__restrict__ cam_idx, int chunk,
+                                                              int *__restrict__ hist) {
+  extern __shared__ int s_hist_all[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int *s_hist = s_hist_all + (size_t)wv * P;
+  const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
+  for (int q = lane; q < P; q += 64) s_hist[q] = 0;
+  wave_sync();
+  const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
+  for (long long a = a0; a < a1; ++a) {
+    const long long o0 = pt_ptr[a];
+    const int d = (int)(pt_ptr[a + 1] - o0);
+    for (int i = 0; i < d; ++i) {
+      const int k = cam_idx[o0 + i];
+      for (int j = i + lane; j < d; j += 64) s_hist[idx_pair_id(k, cam_idx[o0 + j], m)] += 1;  // distinct pairs per instruction
+      wave_sync();
+    }
+  }
+  for (int q = lane; q < P; q += 64) hist[(size_t)w * P + q] = s_hist[q];
+}
+
+// exclusive prefix over the waves, per pair (in place); cnt[q] = total
+__global__ void k_idx_scan(int P, int n_waves, int *__restrict__ hist, long long *__restrict__ cnt) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P) return;
+  long long run = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    const int v = hist[(size_t)w * P + q];
+    hist[(size_t)w * P + q] = (int)run;
+    run += v;
+  }
+  cnt[q] = run;
+}
+
+// the same walk again: item r of pair q goes to sub-list r % S[q], position r / S[q] (the host's dealing)
+__global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m, int P, const long long *__restrict__ pt_ptr,
+                                                             const int *__restrict__ cam_idx, int chunk,
+                                                             const int *__restrict__ hist, const int *__restrict__ S,
+                                                             const int *__restrict__ vp_ptr, const long long *__restrict__ vp_off,
+                                                             int *__restrict__ it_k, int *__restrict__ it_l, int *__restrict__ it_a) {
+  extern __shared__ int s_hist_all[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int *s_rank = s_hist_all + (size_t)wv * P;
+  const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
+  for (int q = lane; q < P; q += 64) s_rank[q] = hist[(size_t)w * P + q];  // items of earlier waves
+  wave_sync();
+  const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
+  for (long long a = a0; a < a1; ++a) {
+    const long long o0 = pt_ptr[a];
+    const int d = (int)(pt_ptr[a + 1] - o0);
+    for (int i = 0; i < d; ++i) {
+      const int k = cam_idx[o0 + i];
+      for (int j = i + lane; j < d; j += 64) {
+        const int q = idx_pair_id(k, cam_idx[o0 + j], m);
+        const int r = s_rank[q];
+        s_rank[q] = r + 1;
+        const int sq = S[q];
+        const long long pos = vp_off[vp_ptr[q] + (r % sq)] + r / sq;
+        it_k[pos] = (int)(o0 + i);
+        it_l[pos] = (int)(o0 + j);
+        it_a[pos] = (int)a;
+      }
+      wave_sync();
+    }
+  }
+}
+
+// lo[v][r] = first item of list v whose point is >= range_lo[r]  (r = 0 .. nR: the last column is the list's end)
+__global__ void k_idx_bounds(int VP, int nR, const long long *__restrict__ vp_off, const long long *__restrict__ range_lo,
+                             const int *__restrict__ it_a, long long *__restrict__ lo) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)VP * (nR + 1)) return;
+  const int v = (int)(t / (nR + 1)), r = (int)(t - (long long)v * (nR + 1));
+  long long b = vp_off[v], e = vp_off[v + 1];
+  const long long key = range_lo[r];
+  while (b < e) {  // lower_bound
+    const long long mid = (b + e) >> 1;
+    if (it_a[mid] < key) b = mid + 1;
+    else e = mid;
+  }
+  lo[t] = b;
+}
+
+// The bounded-skew merge of one wave's 21 lists (see k_schur_slots), lane = slot.  FILL = false: count the steps.
+// FILL = true: write the step-major rows, the pacing table (steps taken when the slowest slot leaves a segment) and
+// the padding rows (record n_obs, point N: the all-zero rows).
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int nSeg, long long skew, long long segG,
+                                                  const long long *__restrict__ sl_beg, const int *__restrict__ sl_len,
+                                                  const long long *__restrict__ range_o0, const int *__restrict__ it_k,
+                                                  const int *__restrict__ it_l, const int *__restrict__ it_a,
+                                                  const long long *__restrict__ w_beg, int pad_obs, int pad_pt,
+                                                  int *__restrict__ w_steps, int *__restrict__ st_k, int *__restrict__ st_l,
+                                                  int *__restrict__ st_a, int *__restrict__ seg_end) {
+  const long long b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool slot = lane < PSTEP;
+  long long cur = slot ? sl_beg[b * PSTEP + lane] : 0;
+  const long long end = slot ? cur + sl_len[b * PSTEP + lane] : 0;
+  const long long o_lo = range_o0[b % nR];
+  const long long base = FILL ? w_beg[b] : 0;
+  constexpr long long NONE = 1LL << 40;
+  int steps = 0, sg = 0;
+  // two keys ahead in registers: the next step's key never waits for a load issued in this step
+  long long k0 = cur < end ? it_k[cur] : NONE, k1 = cur + 1 < end ? it_k[cur + 1] : NONE;
+  while (true) {
+    long long lo = k0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lo = min(lo, __shfl_xor(lo, off, 64));
+    if (FILL && lo < NONE && lane == 0)
+      while (sg < nSeg && lo >= o_lo + (sg + 1) * segG) seg_end[b * nSeg + sg++] = steps;
+    if (lo >= NONE) break;
+    const bool take = k0 < NONE && k0 <= lo + skew;
+    if (FILL && slot) {
+      const long long o = (base + steps) * PSTEP + lane;
+      st_k[o] = take ? (int)k0 : pad_obs;
+      st_l[o] = take ? it_l[cur] : pad_obs;
+      st_a[o] = take ? it_a[cur] : pad_pt;
+    }
+    if (take) {
+      ++cur;
+      k0 = k1;
+      k1 = cur + 1 < end ? it_k[cur + 1] : NONE;
+    }
+    ++steps;
+  }
+  if (FILL) {
+    if (lane == 0)
+      while (sg < nSeg) seg_end[b * nSeg + sg++] = steps;
+  } else if (lane == 0) {
+    w_steps[b] = steps;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host side
@@ -2192,6 +2339,7 @@ struct mvba_handle {
   bool slot_pace = true;
   int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
   int *d_seg_end = nullptr, *d_prog = nullptr;
+  bool index_on_device = false;       // the slot form's index was built by the k_idx_* kernels (nothing to upload)
   long long *d_trace = nullptr;       // -DMVBA_SLOT_TRACE builds with MVBA_SLOT_TRACE=<file>: per-wave timings of the last launch
   int4 *d_wdesc = nullptr;
   int *d_wunits = nullptr;
@@ -2452,6 +2600,14 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (e != hipSuccess) { delete h; return fail(MVBA_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e)); }
   }
   h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7; h->ld = (h->D + 3) & ~3;
+#define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+  // the topology goes up first: the Schur index is built from it on the device
+  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRY(dmalloc(&h->d_pt_ptr, N + 1));
+  TRY(dmalloc(&h->d_cam, nobs));
+  TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
+  if (nobs) TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
 
   // Schur launch geometry (measured sweep at config 3, profiles/): ~800 camera-list entries per
   // block is the optimum (tail balance vs strip flush); small problems still get >= 2048 blocks
@@ -2517,6 +2673,26 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       body(0);
       for (auto &x : th) x.join();
     };
+    // The index is built on the DEVICE (k_idx_*) when a wave's pair histogram fits LDS (P ints x 4 waves per block:
+    // up to ~138 cameras) and the slot form will use it; MVBA_INDEX=host keeps the host threads (the test that the
+    // two builds are identical).  The unit form of larger camera counts is still sorted on the host.
+    bool dev_build = (size_t)P * sizeof(int) * IDX_WAVES <= 150 * 1024 && N > 0 && nobs > 0 &&
+                     !(getenv("MVBA_INDEX") && !strcmp(getenv("MVBA_INDEX"), "host"));
+    const int idx_chunk = (int)std::max<long long>(32, (N + 4095) / 4096);           // points per wave
+    const long long idx_waves = dev_build ? ((N + idx_chunk - 1) / idx_chunk + IDX_WAVES - 1) / IDX_WAVES * IDX_WAVES : 0;
+    int *d_hist = nullptr;
+    long long *d_cnt = nullptr;
+    if (dev_build) {
+      TRY(dmalloc(&d_hist, (size_t)idx_waves * P));
+      TRY(dmalloc(&d_cnt, (size_t)P));
+      TRYH(hipFuncSetAttribute((const void *)k_idx_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P * sizeof(int) * IDX_WAVES)));
+      TRYH(hipFuncSetAttribute((const void *)k_idx_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P * sizeof(int) * IDX_WAVES)));
+      hipLaunchKernelGGL(k_idx_count, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), P * sizeof(int) * IDX_WAVES, h->stream, N, m,
+                         (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist);
+      hipLaunchKernelGGL(k_idx_scan, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, h->stream, (int)P, (int)idx_waves, d_hist, d_cnt);
+      TRYH(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(long long) * P, hipMemcpyDeviceToHost, h->stream));
+      TRYH(hipStreamSynchronize(h->stream));
+    } else
     on_threads([&](int tid) {
       for (long long a = 0; a < N; ++a) {
         const int *cb = p->cam_idx + p->pt_ptr[a];
@@ -2588,6 +2764,26 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     for (long long q = 0; q < P; ++q)
       for (int sI = 0; sI < S[q]; ++sI) vp_off[vp_ptr[q] + sI + 1] = (cnt[q] - sI + S[q] - 1) / S[q];
     for (int v = 0; v < VP; ++v) vp_off[v + 1] += vp_off[v];
+    // the window-equalised merge (MVBA_SLOT_WINDOW, an experiment) exists on the host only
+    const bool dev_items = dev_build && slots && h->slot_window >= (1LL << 39);
+    int *d_pk = nullptr, *d_pl = nullptr, *d_pa = nullptr, *d_S = nullptr, *d_vp_ptr = nullptr;
+    long long *d_vp_off = nullptr;
+    auto free_dev_tmp = [&]() {
+      for (void *q : {(void *)d_hist, (void *)d_cnt, (void *)d_pk, (void *)d_pl, (void *)d_pa, (void *)d_S, (void *)d_vp_ptr, (void *)d_vp_off})
+        if (q) hipFree(q);
+      d_hist = nullptr; d_cnt = nullptr; d_pk = d_pl = d_pa = d_S = d_vp_ptr = nullptr; d_vp_off = nullptr;
+    };
+    if (dev_items) {
+      TRY(dmalloc(&d_pk, (size_t)T)); TRY(dmalloc(&d_pl, (size_t)T)); TRY(dmalloc(&d_pa, (size_t)T));
+      TRY(dmalloc(&d_S, (size_t)P)); TRY(dmalloc(&d_vp_ptr, (size_t)P + 1)); TRY(dmalloc(&d_vp_off, (size_t)VP + 1));
+      TRYH(hipMemcpyAsync(d_S, S.data(), sizeof(int) * P, hipMemcpyHostToDevice, h->stream));
+      TRYH(hipMemcpyAsync(d_vp_ptr, vp_ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
+      TRYH(hipMemcpyAsync(d_vp_off, vp_off.data(), sizeof(long long) * (VP + 1), hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(k_idx_fill, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), P * sizeof(int) * IDX_WAVES, h->stream, N, m,
+                         (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_S, d_vp_ptr, d_vp_off, d_pk, d_pl, d_pa);
+      TRYH(hipGetLastError());
+    } else {
+      if (dev_build) { hipFree(d_hist); hipFree(d_cnt); d_hist = nullptr; d_cnt = nullptr; }
     it_k.resize(T); it_l.resize(T); it_a.resize(T);
     {
       std::vector<long long> run(P, 0);
@@ -2609,19 +2805,33 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
       });
     }
+    }
     lap("items sorted by pair");
     // units: (pair, sub-list, point range), numbered pair-major (k_schur_reduce sums them in this order)
     unit_ptr.assign(P + 1, 0);
     std::vector<int> uid((size_t)VP * nR, -1);
+    std::vector<long long> lo_tab;  // device build: lower bounds of every list at every range boundary
+    if (dev_items) {
+      long long *d_rl = nullptr, *d_lo = nullptr;
+      TRY(dmalloc(&d_rl, (size_t)nR + 1)); TRY(dmalloc(&d_lo, (size_t)VP * (nR + 1)));
+      TRYH(hipMemcpyAsync(d_rl, range_lo.data(), sizeof(long long) * (nR + 1), hipMemcpyHostToDevice, h->stream));
+      const long long nt = (long long)VP * (nR + 1);
+      hipLaunchKernelGGL(k_idx_bounds, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, VP, nR, d_vp_off, d_rl, d_pa, d_lo);
+      lo_tab.resize(nt);
+      TRYH(hipMemcpyAsync(lo_tab.data(), d_lo, sizeof(long long) * nt, hipMemcpyDeviceToHost, h->stream));
+      TRYH(hipStreamSynchronize(h->stream));
+      hipFree(d_rl); hipFree(d_lo);
+    }
     for (int k = 0; k < m; ++k)
       for (int l = k; l < m; ++l) {
         const long long q = pair_id(k, l);
         unit_ptr[q] = (int)units.size();
         for (int sI = 0; sI < S[q]; ++sI) {
           const int v = vp_ptr[q] + sI;
-          const int *b = it_a.data() + vp_off[v], *e = it_a.data() + vp_off[v + 1];
+          const int *b = it_a.data() + (dev_items ? 0 : vp_off[v]), *e = it_a.data() + (dev_items ? 0 : vp_off[v + 1]);
           for (int r = 0; r < nR; ++r) {
-            const long long lo = std::lower_bound(b, e, range_lo[r]) - it_a.data(), hi = std::lower_bound(b, e, range_lo[r + 1]) - it_a.data();
+            const long long lo = dev_items ? lo_tab[(size_t)v * (nR + 1) + r] : std::lower_bound(b, e, range_lo[r]) - it_a.data();
+            const long long hi = dev_items ? lo_tab[(size_t)v * (nR + 1) + r + 1] : std::lower_bound(b, e, range_lo[r + 1]) - it_a.data();
             if (hi <= lo) continue;
             uid[(size_t)v * nR + r] = (int)units.size();
             units.push_back(make_int4((int)(lo & 0xffffffffLL), (int)(lo >> 32), (int)(hi - lo), (k << 16) | l));
@@ -2720,6 +2930,37 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
           while (sg < nSeg) seg_end[(size_t)b * nSeg + sg++] = (int)steps;
         return steps;
       };
+      // device merge: the slots' list spans (from the units) go up, the step counts come back
+      long long *d_slbeg = nullptr, *d_ro0 = nullptr, *d_wbeg = nullptr;
+      int *d_sllen = nullptr, *d_wsteps = nullptr;
+      if (dev_items) {
+        std::vector<long long> sl_beg((size_t)n_waves * PSTEP, 0), ro0(nR);
+        std::vector<int> sl_len((size_t)n_waves * PSTEP, 0);
+        for (int r = 0; r < nR; ++r) ro0[r] = p->pt_ptr[range_lo[r]];
+        for (long long b = 0; b < n_waves; ++b) {
+          int vs[PSTEP];
+          const int r = wave_lists(b, vs);
+          for (int sl = 0; sl < PSTEP; ++sl) {
+            const int id = vs[sl] >= 0 ? uid[(size_t)vs[sl] * nR + r] : -1;
+            wunits[(size_t)b * PSTEP + sl] = id;
+            if (id < 0) continue;
+            sl_beg[(size_t)b * PSTEP + sl] = ((long long)units[id].y << 32) | (unsigned)units[id].x;
+            sl_len[(size_t)b * PSTEP + sl] = units[id].z;
+          }
+        }
+        TRY(dmalloc(&d_slbeg, sl_beg.size())); TRY(dmalloc(&d_sllen, sl_len.size())); TRY(dmalloc(&d_ro0, (size_t)nR));
+        TRY(dmalloc(&d_wsteps, (size_t)n_waves)); TRY(dmalloc(&d_wbeg, (size_t)n_waves + 1));
+        TRYH(hipMemcpyAsync(d_slbeg, sl_beg.data(), sizeof(long long) * sl_beg.size(), hipMemcpyHostToDevice, h->stream));
+        TRYH(hipMemcpyAsync(d_sllen, sl_len.data(), sizeof(int) * sl_len.size(), hipMemcpyHostToDevice, h->stream));
+        TRYH(hipMemcpyAsync(d_ro0, ro0.data(), sizeof(long long) * nR, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_idx_merge<false>, dim3((unsigned)n_waves), dim3(64), 0, h->stream, n_waves, nR, nSeg, skew, segG, d_slbeg, d_sllen,
+                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, (int)nobs, (int)N, d_wsteps, (int *)nullptr, (int *)nullptr, (int *)nullptr,
+                           (int *)nullptr);
+        std::vector<int> ws32(n_waves);
+        TRYH(hipMemcpyAsync(ws32.data(), d_wsteps, sizeof(int) * n_waves, hipMemcpyDeviceToHost, h->stream));
+        TRYH(hipStreamSynchronize(h->stream));  // (sl_beg / sl_len / ro0 live until here)
+        for (long long b = 0; b < n_waves; ++b) win_steps[(size_t)b * nWin] = ws32[b];
+      } else
       on_threads([&](int tid) {
         for (long long b = tid; b < n_waves; b += n_thr) merge(b, 0, false);
       });
@@ -2741,11 +2982,25 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       for (long long b = 0; b < n_waves; ++b) w_beg[b + 1] = w_beg[b] + w_steps[b];
       const long long total_steps = w_beg[n_waves];
       if (total_steps * PSTEP >= (1LL << 40)) { mvba_destroy(h); return fail(MVBA_ERR_BADARG, "too many (point, camera pair) items"); }
+      if (dev_items) {  // the step-major arrays are written where the kernel will read them
+        const size_t rows = (size_t)total_steps * PSTEP;
+        TRY(dmalloc(&h->d_it_k, rows)); TRY(dmalloc(&h->d_it_l, rows)); TRY(dmalloc(&h->d_it_a, rows));
+        TRY(dmalloc(&h->d_seg_end, seg_end.size()));
+        TRYH(hipMemcpyAsync(d_wbeg, w_beg.data(), sizeof(long long) * (n_waves + 1), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_idx_merge<true>, dim3((unsigned)n_waves), dim3(64), 0, h->stream, n_waves, nR, nSeg, skew, segG, d_slbeg, d_sllen,
+                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, (int)nobs, (int)N, d_wsteps, h->d_it_k, h->d_it_l, h->d_it_a, h->d_seg_end);
+        TRYH(hipGetLastError());
+        TRYH(hipStreamSynchronize(h->stream));
+        for (void *q : {(void *)d_slbeg, (void *)d_sllen, (void *)d_ro0, (void *)d_wsteps, (void *)d_wbeg}) hipFree(q);
+        free_dev_tmp();
+        h->index_on_device = true;
+      } else {
       st_k.resize(total_steps * PSTEP); st_l.resize(total_steps * PSTEP); st_a.resize(total_steps * PSTEP);
       on_threads([&](int tid) {
         for (long long b = tid; b < n_waves; b += n_thr)
           if (w_steps[b]) merge(b, w_beg[b], true);
       });
+      }
       lap("slot merge (fill)");
       const int w_off_ = w_off;
       std::vector<int> live(nR, 0);  // waves of a range that run at all: what a pacing counter has to reach
@@ -2767,7 +3022,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         }
 #endif
       h->n_slot_items = total_steps * PSTEP;
-      it_k.swap(st_k); it_l.swap(st_l); it_a.swap(st_a);  // what is uploaded below: the step-major arrays
+      if (!dev_items) { it_k.swap(st_k); it_l.swap(st_l); it_a.swap(st_a); }  // what is uploaded below: the step-major arrays
       std::vector<int>().swap(st_k); std::vector<int>().swap(st_l); std::vector<int>().swap(st_a);
     } else {
     // work queues: strip k on XCD k % 8, inside a queue by (k, range, l, sub-list)
@@ -2803,11 +3058,6 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
   h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks
 
-#define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
-#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  TRY(dmalloc(&h->d_pt_ptr, N + 1));
-  TRY(dmalloc(&h->d_cam, nobs));
   TRY(dmalloc(&h->d_obs_pt, nobs));
   TRY(dmalloc(&h->d_xy, nobs));
   TRY(dmalloc(&h->d_csc, csc.size()));
@@ -2843,9 +3093,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_bar, 1));
   TRYH(hipHostMalloc((void **)&h->h_cost, 2 * sizeof(double)));
   h->h_flag = reinterpret_cast<int *>(h->h_cost + 1);  // cost and flags come back in one copy
-  TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
   if (nobs) {
-    TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_obs_pt, obs_pt.data(), sizeof(int) * nobs, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
     if (want_strip) TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
@@ -2857,15 +3105,16 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   if (h->use_pairs) {
     const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
-    TRY(dmalloc(&h->d_it_k, it_k.size())); TRY(dmalloc(&h->d_it_l, it_l.size())); TRY(dmalloc(&h->d_it_a, it_a.size()));
+    if (!h->index_on_device) { TRY(dmalloc(&h->d_it_k, it_k.size())); TRY(dmalloc(&h->d_it_l, it_l.size())); TRY(dmalloc(&h->d_it_a, it_a.size())); }
     TRY(dmalloc(&h->d_units, units.size())); TRY(dmalloc(&h->d_unit_ptr, P1));
     TRY(dmalloc(&h->d_q_ptr, 9)); TRY(dmalloc(&h->d_q_units, q_units.size())); TRY(dmalloc(&h->d_q_head, 64));
     TRY(dmalloc(&h->d_wdesc, wdesc.size())); TRY(dmalloc(&h->d_wunits, wunits.size()));
 #ifdef MVBA_SLOT_TRACE
     if (getenv("MVBA_SLOT_TRACE")) { TRY(dmalloc(&h->d_trace, 8 * std::max<size_t>(1, wdesc.size()))); TRYH(hipMemset(h->d_trace, 0, 64 * std::max<size_t>(1, wdesc.size()))); }
 #endif
-    TRY(dmalloc(&h->d_seg_end, seg_end.size())); TRY(dmalloc(&h->d_prog, (size_t)h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
-    if (!seg_end.empty()) TRYH(hipMemcpy(h->d_seg_end, seg_end.data(), sizeof(int) * seg_end.size(), hipMemcpyHostToDevice));
+    if (!h->index_on_device) TRY(dmalloc(&h->d_seg_end, seg_end.size()));
+    TRY(dmalloc(&h->d_prog, (size_t)h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
+    if (!seg_end.empty() && !h->index_on_device) TRYH(hipMemcpy(h->d_seg_end, seg_end.data(), sizeof(int) * seg_end.size(), hipMemcpyHostToDevice));
     if (!wdesc.empty()) {
       TRYH(hipMemcpy(h->d_wdesc, wdesc.data(), sizeof(int4) * wdesc.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_wunits, wunits.data(), sizeof(int) * wunits.size(), hipMemcpyHostToDevice));
@@ -3344,6 +3593,10 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
     case MVBA_BUF_DXI: cnt = n9; break;
     case MVBA_BUF_DX: case MVBA_BUF_TRIAL_X: cnt = 3 * h->N; break;
     case MVBA_BUF_TRIAL_CAM: cnt = (long long)CAM_IN * h->m; break;
+    case MVBA_BUF_INDEX_K: case MVBA_BUF_INDEX_L: case MVBA_BUF_INDEX_A:
+      cnt = h->schur_mode == SCHUR_SLOTS ? h->n_slot_items : (h->schur_mode == SCHUR_PAIRS ? h->n_items : 0);
+      break;
+    case MVBA_BUF_INDEX_SEG: cnt = h->schur_mode == SCHUR_SLOTS ? (long long)h->n_waves * h->slot_nseg : 0; break;
     default: return fail(MVBA_ERR_BADARG, "unknown buffer id");
   }
   *n = cnt;
@@ -3401,6 +3654,11 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
     MVBA_HIP(d2h(h->d_X[1 - h->cur], sizeof(double) * cnt));
   } else if (which == MVBA_BUF_TRIAL_CAM) {
     MVBA_HIP(d2h(h->d_cam15[1 - h->cur], sizeof(double) * cnt));
+  } else if (which >= MVBA_BUF_INDEX_K && which <= MVBA_BUF_INDEX_SEG) {  // the Schur index as the kernel reads it (ints, widened)
+    const int *src = which == MVBA_BUF_INDEX_K ? h->d_it_k : (which == MVBA_BUF_INDEX_L ? h->d_it_l : (which == MVBA_BUF_INDEX_A ? h->d_it_a : h->d_seg_end));
+    std::vector<int> tmp((size_t)cnt);
+    if (cnt) MVBA_HIP(hipMemcpy(tmp.data(), src, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < cnt; ++i) out[i] = (double)tmp[i];
   }
   return MVBA_OK;
 }

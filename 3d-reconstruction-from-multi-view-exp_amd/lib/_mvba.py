@@ -18,7 +18,7 @@ MVBA_OK, MVBA_ERR_BADARG, MVBA_ERR_SINGULAR, MVBA_ERR_HIP, MVBA_ERR_RCCL, MVBA_E
 
 KERNEL_IDS = ("resid_jac", "point_blocks", "point_inv", "schur", "allreduce", "solve", "backsub_cost", "cost")
 BUF = {"residual": 0, "JX": 1, "JC": 2, "E": 3, "dP": 4, "A_full": 5, "b_full": 6, "dxi": 7, "dX": 8,
-       "trial_X": 9, "trial_cam": 10}
+       "trial_X": 9, "trial_cam": 10, "index_k": 11, "index_l": 12, "index_a": 13, "index_seg": 14}
 
 _dp = C.POINTER(C.c_double)
 

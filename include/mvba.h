@@ -153,7 +153,11 @@ enum {
   MVBA_BUF_DXI,          /* [9m] with zeros at the gauge slots               */
   MVBA_BUF_DX,           /* [n_points][3]                                    */
   MVBA_BUF_TRIAL_X,      /* [n_points][3]                                    */
-  MVBA_BUF_TRIAL_CAM     /* [m][15]  f,u,v,t[3],R[9]                         */
+  MVBA_BUF_TRIAL_CAM,    /* [m][15]  f,u,v,t[3],R[9]                         */
+  MVBA_BUF_INDEX_K,      /* the Schur index as the kernel reads it: k-side observation of every item row */
+  MVBA_BUF_INDEX_L,      /*   l-side observation                                                          */
+  MVBA_BUF_INDEX_A,      /*   point (slot form: step-major rows incl. padding; unit form: pair-major)      */
+  MVBA_BUF_INDEX_SEG     /*   slot form: pacing table [waves][segments]                                   */
 };
 int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity, int64_t *n);
 

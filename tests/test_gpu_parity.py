@@ -719,3 +719,25 @@ def test_config4_in_full_on_one_gpu():
                  f"{info['units']} units): {dt / 2 * 1e3:.2f} ms per LM iteration ({solves} solves in 2 iterations); "
                  f"ms per solve: {per}; scene generation {t_gen:.1f} s, engine create {t_create:.1f} s")
     full.close()
+
+
+@pytest.mark.parametrize("n,m,p", [(60_000, 24, 0.3), (4_000, 100, 0.1), (90, 70, 1.0)])
+def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypatch):
+    """mvba_create builds the slot form's index with kernels (stable counting sort by pair, dealing into
+    sub-lists, bounded-skew merge into step-major rows, pacing table); MVBA_INDEX=host keeps round 2's host
+    threads.  The two builds must give the kernel the same arrays, entry for entry."""
+    sc = make_scene(n, m, vis_p=p)
+
+    def build():
+        ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                              sc.init_R, sc.init_t, axis=sc.axis)
+        eng = ba._engine
+        assert eng.schur_info()["kernel"] == "slots"
+        return {k: eng.debug_read(k) for k in ("index_k", "index_l", "index_a", "index_seg")}, eng.schur_info()
+
+    dev, info_d = build()
+    monkeypatch.setenv("MVBA_INDEX", "host")
+    host, info_h = build()
+    assert info_d == info_h and info_d["slot_rows"] > 0
+    for k in dev:
+        np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
