@@ -8,7 +8,7 @@
 //   K3  k_schur_pairs + k_schur_reduce (k_schur_strip behind MVBA_SCHUR=strip)
 //                        A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
 //   C1  ncclAllReduce    [A|b] across point shards                            
-//   K4  k_chol_super / k_chol_trail32 / k_chol_backsolve_all (+ k_lu_solve rescue)
+//   K4  k_chol_super / k_chol_trail32 / k_chol_backsolve_all (+ the k_lu_* rescue)
 //                        dense solve of the gauge-reduced system              (ref :146)
 //   K5+K6 k_backsub, k_cost  dX_a, trial state, trial cost                    (ref :152-162, :260-281, :666-677)
 // HBM layout: observations sorted by point (CSR).  The linearisation of ONE
@@ -1873,30 +1873,41 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
 
 // ---- fallback: LU with partial pivoting (what np.linalg.solve / LAPACK gesv does, ref :146) ----
 // Only reached when the Cholesky meets a non-positive pivot (reduced system not positive definite,
-// e.g. a negative damping factor).  Slow (one workgroup, D sequential steps) but rare.
+// e.g. a negative damping factor): rare, but a library path, so it is blocked and runs on the whole
+// chip (round 2's single-workgroup kernel took 0.11 s at D = 893 and 13 s at D = 4493).
+// Right-looking, panels of LU_NB columns, on the AUGMENTED matrix [F | rhs] (ld = D + 1: the row
+// swaps, the triangular solve and the trailing update carry the forward substitution along):
+//   k_lu_panel  one workgroup: partial pivoting inside the panel (rows swapped in the panel only)
+//   k_lu_swap   the panel's row swaps on every other column
+//   k_lu_trsm   U12 = L11^-1 A12 (a thread per column)
+//   k_lu_gemm   A22 -= L21 U12 (64 x 64 tiles, K = LU_NB through LDS)
+// then k_lu_backsub solves U x = y row by row.
+constexpr int LU_NB = 32;
+
 __global__ void k_compact_full(int D, int m, int gauge_axis, const double *__restrict__ Apk,
-                               const double *__restrict__ bfull, double *__restrict__ F, double *__restrict__ rhs) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-  if (j >= D) return;
-  const int gi = keep_index(i, gauge_axis), gj = keep_index(j, gauge_axis);
+                               const double *__restrict__ bfull, double *__restrict__ F) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // j in [0, D]: column D is the right-hand side
+  if (j > D) return;
+  const int gi = keep_index(i, gauge_axis);
+  if (j == D) { F[(size_t)i * (D + 1) + D] = bfull[gi]; return; }
+  const int gj = keep_index(j, gauge_axis);
   const int r = min(gi, gj), c = max(gi, gj);
   const int k = r / 9;
-  F[(size_t)i * D + j] = Apk[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
-  if (j == 0) rhs[i] = bfull[gi];
+  F[(size_t)i * (D + 1) + j] = Apk[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
 }
 
-__global__ __launch_bounds__(1024) void k_lu_solve(double *__restrict__ F, double *__restrict__ rhs, int D, int m,
-                                                   int gauge_axis, double *__restrict__ dxi_full, int *__restrict__ flag) {
+__global__ __launch_bounds__(1024) void k_lu_panel(double *__restrict__ F, int D, int j0, int nb, int *__restrict__ ipiv,
+                                                   int *__restrict__ flag) {
   __shared__ double s_val[1024];
   __shared__ int s_idx[1024];
   __shared__ int s_piv;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int k = 0; k < D; ++k) {
-    // pivot search in column k
+  const int tid = threadIdx.x, nt = blockDim.x, ld = D + 1;
+  for (int c = 0; c < nb; ++c) {
+    const int col = j0 + c;
     double best = -1.0;
-    int bi = k;
-    for (int i = k + tid; i < D; i += nt) {
-      const double v = fabs(F[(size_t)i * D + k]);
+    int bi = col;
+    for (int i = col + tid; i < D; i += nt) {
+      const double v = fabs(F[(size_t)i * ld + col]);
       if (v > best) { best = v; bi = i; }
     }
     s_val[tid] = best; s_idx[tid] = bi;
@@ -1909,40 +1920,112 @@ __global__ __launch_bounds__(1024) void k_lu_solve(double *__restrict__ F, doubl
     }
     if (tid == 0) {
       s_piv = s_idx[0];
+      ipiv[col] = s_idx[0];
       if (!(s_val[0] > 0.0)) atomicOr(flag, 4);  // exactly singular: LAPACK's info > 0 -> LinAlgError
     }
     __syncthreads();
     const int p = s_piv;
-    if (p != k) {  // swap rows k and p (and the right-hand side)
-      for (int j = tid; j < D; j += nt) {
-        const double a = F[(size_t)k * D + j];
-        F[(size_t)k * D + j] = F[(size_t)p * D + j];
-        F[(size_t)p * D + j] = a;
-      }
-      if (tid == 0) { const double a = rhs[k]; rhs[k] = rhs[p]; rhs[p] = a; }
+    if (p != col && tid < nb) {  // swap inside the panel (k_lu_swap does the other columns)
+      const double a = F[(size_t)col * ld + j0 + tid];
+      F[(size_t)col * ld + j0 + tid] = F[(size_t)p * ld + j0 + tid];
+      F[(size_t)p * ld + j0 + tid] = a;
     }
     __syncthreads();
-    const double piv = F[(size_t)k * D + k];
-    for (int i = k + 1 + tid; i < D; i += nt) F[(size_t)i * D + k] /= piv;  // multipliers
-    __syncthreads();
-    const int rem = D - k - 1;
-    for (long long q = tid; q < (long long)rem * rem; q += nt) {  // rank-1 update of the trailing block
-      const int i = k + 1 + (int)(q / rem), j = k + 1 + (int)(q % rem);
-      F[(size_t)i * D + j] -= F[(size_t)i * D + k] * F[(size_t)k * D + j];
+    const double ipv = 1.0 / F[(size_t)col * ld + col];
+    const int rem = nb - c - 1;  // panel columns right of this one
+    // multipliers and the rank-1 update of the rest of the panel, one row per (rem + 1) consecutive threads' work
+    for (long long q = tid; q < (long long)(D - col - 1) * (rem + 1); q += nt) {
+      const int i = col + 1 + (int)(q / (rem + 1)), cc = (int)(q % (rem + 1));
+      const double mult = F[(size_t)i * ld + col] * ipv;
+      if (cc == 0) ;  // (the multiplier itself is stored after the update below: other threads of the row still read the old value)
+      else F[(size_t)i * ld + col + cc] -= mult * F[(size_t)col * ld + col + cc];
     }
-    for (int i = k + 1 + tid; i < D; i += nt) rhs[i] -= F[(size_t)i * D + k] * rhs[k];  // forward substitution
+    __syncthreads();
+    for (int i = col + 1 + tid; i < D; i += nt) F[(size_t)i * ld + col] *= ipv;
     __syncthreads();
   }
-  for (int k = D - 1; k >= 0; --k) {  // back substitution with U
-    if (tid == 0) rhs[k] /= F[(size_t)k * D + k];
-    __syncthreads();
-    const double xk = rhs[k];
-    for (int i = tid; i < k; i += nt) rhs[i] -= F[(size_t)i * D + k] * xk;
+}
+
+__global__ void k_lu_swap(double *__restrict__ F, int D, int j0, int nb, const int *__restrict__ ipiv) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;  // every column of [F | rhs] outside the panel
+  if (j >= j0) j += nb;
+  if (j > D) return;
+  const int ld = D + 1;
+  for (int c = 0; c < nb; ++c) {
+    const int r = j0 + c, p = ipiv[r];
+    if (p != r) {
+      const double a = F[(size_t)r * ld + j];
+      F[(size_t)r * ld + j] = F[(size_t)p * ld + j];
+      F[(size_t)p * ld + j] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lu_trsm(double *__restrict__ F, int D, int j0, int nb) {
+  __shared__ double L[LU_NB][LU_NB + 1];
+  const int ld = D + 1;
+  for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) L[e / nb][e % nb] = F[(size_t)(j0 + e / nb) * ld + j0 + e % nb];
+  __syncthreads();
+  const int j = j0 + nb + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > D) return;
+  double u[LU_NB];
+  for (int c = 0; c < nb; ++c) {
+    double v = F[(size_t)(j0 + c) * ld + j];
+    for (int cc = 0; cc < c; ++cc) v -= L[c][cc] * u[cc];
+    u[c] = v;
+    F[(size_t)(j0 + c) * ld + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lu_gemm(double *__restrict__ F, int D, int j0, int nb) {
+  __shared__ double sL[64][LU_NB + 1], sU[LU_NB][65];
+  const int ld = D + 1, i0 = j0 + nb + blockIdx.y * 64, c0 = j0 + nb + blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * nb; e += 256) {
+    const int r = e / nb, k = e % nb;
+    sL[r][k] = (i0 + r < D) ? F[(size_t)(i0 + r) * ld + j0 + k] : 0.0;
+  }
+  for (int e = threadIdx.x; e < nb * 64; e += 256) {
+    const int k = e >> 6, c = e & 63;
+    sU[k][c] = (c0 + c <= D) ? F[(size_t)(j0 + k) * ld + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+  double acc[4][4] = {};
+  for (int k = 0; k < nb; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = sL[tr + 16 * u][k];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = sU[k][tc + 16 * v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + tr + 16 * u, c = c0 + tc + 16 * v;
+      if (i < D && c <= D) F[(size_t)i * ld + c] -= acc[u][v];
+    }
+}
+
+// U x = y (y = column D of the factored augmented matrix), row by row from the bottom; then the gauge slots
+__global__ __launch_bounds__(1024) void k_lu_backsub(double *__restrict__ F, int D, int m, int gauge_axis,
+                                                     double *__restrict__ dxi_full) {
+  __shared__ double s_red[16];
+  const int tid = threadIdx.x, nt = blockDim.x, ld = D + 1;
+  for (int k = D - 1; k >= 0; --k) {
+    double part = 0.0;
+    for (int j = k + 1 + tid; j < D; j += nt) part += F[(size_t)k * ld + j] * F[(size_t)j * ld + D];
+    const double t = block_sum(part, s_red);
+    if (tid == 0) F[(size_t)k * ld + D] = (F[(size_t)k * ld + D] - t) / F[(size_t)k * ld + k];
     __syncthreads();
   }
   for (int i = tid; i < 9 * m; i += nt) dxi_full[i] = 0.0;
   __syncthreads();
-  for (int i = tid; i < D; i += nt) dxi_full[keep_index(i, gauge_axis)] = rhs[i];
+  for (int i = tid; i < D; i += nt) dxi_full[keep_index(i, gauge_axis)] = F[(size_t)i * ld + D];
 }
 
 // ------------------------------------------------------------------ K6a: trial cameras (ref :263-281, utils.py:10-29)
@@ -2359,6 +2442,7 @@ struct mvba_handle {
   double *d_PL = nullptr, *d_PB = nullptr;
   // reduced system: [A (9m x 9m) | b (9m)] contiguous for the all-reduce
   double *d_Ab = nullptr, *d_Ared = nullptr, *d_Ztiles = nullptr, *d_Lblk = nullptr, *d_dxi = nullptr, *d_dX = nullptr, *d_lu = nullptr;
+  int *d_ipiv = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
   int n_partials = 0, cost_grid = 0;
@@ -3192,7 +3276,7 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
-                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace};
+                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -3412,16 +3496,25 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     // negative damping factor).  The reference's np.linalg.solve is LU with partial pivoting and
     // does not care, so redo the solve that way (slow path, rare) and the tail of the step.
     if (!h->d_lu) {
-      int rc_ = dmalloc(&h->d_lu, (size_t)D * D + D);
+      int rc_ = dmalloc(&h->d_lu, (size_t)D * (D + 1));
+      if (rc_) return rc_;
+      rc_ = dmalloc(&h->d_ipiv, (size_t)D);
       if (rc_) return rc_;
     }
     MVBA_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
     {
       Timed t(h, MVBA_K_SOLVE);
-      hipLaunchKernelGGL(k_compact_full, dim3((D + 255) / 256, D), dim3(256), 0, h->stream, D, m, h->gauge_axis, d_A, d_b,
-                         h->d_lu, h->d_lu + (size_t)D * D);
-      hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), 0, h->stream, h->d_lu, h->d_lu + (size_t)D * D, D, m,
-                         h->gauge_axis, h->d_dxi, h->d_flag);
+      hipLaunchKernelGGL(k_compact_full, dim3((D + 1 + 255) / 256, D), dim3(256), 0, h->stream, D, m, h->gauge_axis, d_A, d_b, h->d_lu);
+      for (int j0 = 0; j0 < D; j0 += LU_NB) {
+        const int nb = std::min(LU_NB, D - j0), right = D + 1 - (j0 + nb);  // columns right of the panel incl. the rhs
+        hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, h->stream, h->d_lu, D, j0, nb, h->d_ipiv, h->d_flag);
+        hipLaunchKernelGGL(k_lu_swap, dim3((D + 1 - nb + 255) / 256), dim3(256), 0, h->stream, h->d_lu, D, j0, nb, h->d_ipiv);
+        if (right > 0) hipLaunchKernelGGL(k_lu_trsm, dim3((right + 255) / 256), dim3(256), 0, h->stream, h->d_lu, D, j0, nb);
+        const int below = D - (j0 + nb);
+        if (below > 0)
+          hipLaunchKernelGGL(k_lu_gemm, dim3((right + 63) / 64, (below + 63) / 64), dim3(256), 0, h->stream, h->d_lu, D, j0, nb);
+      }
+      hipLaunchKernelGGL(k_lu_backsub, dim3(1), dim3(1024), 0, h->stream, h->d_lu, D, m, h->gauge_axis, h->d_dxi);
     }
     h->stats.n_lu_fallback++;
     launch_tail();

@@ -393,13 +393,15 @@ def test_extreme_camera_counts_vs_oracle(n, m, p):
     assert eng.stats()["counts"]["lu_fallback"] == 0
 
 
-def test_indefinite_reduced_system_takes_the_lu_path_like_numpy():
+@pytest.mark.parametrize("n,m,p", [(400, 6, 0.7), (2500, 75, 0.2)])  # D = 47: one panel; D = 668: 21 panels, ragged tiles
+def test_indefinite_reduced_system_takes_the_lu_path_like_numpy(n, m, p):
     """np.linalg.solve (ref :146) is LU with partial pivoting and happily solves an indefinite
-    system; the engine's Cholesky cannot, so it must fall back to its own pivoted LU and agree."""
-    sc = make_scene(400, 6, vis_p=0.7)
-    ba = BundleAdjuster.from_observations(sc.n_points, 6, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+    system; the engine's Cholesky cannot, so it must fall back to its own pivoted LU (blocked,
+    chip-wide: k_lu_panel / swap / trsm / gemm / backsub) and agree."""
+    sc = make_scene(n, m, vis_p=p)
+    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                           sc.init_R, sc.init_t, axis=sc.axis)
-    g = O.OracleEngine(sc.n_points, 6, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    g = O.OracleEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
     g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
     eng = ba._engine
@@ -408,9 +410,9 @@ def test_indefinite_reduced_system_takes_the_lu_path_like_numpy():
     E1, E1o = eng.try_step(c), g.try_step(c)
     assert np.linalg.eigvalsh(g.A).min() < 0 < np.linalg.eigvalsh(g.A).max()
     assert eng.stats()["counts"]["lu_fallback"] == 1
-    dxi = np.zeros(54); dxi[g.keep] = g.dxi_red
-    np.testing.assert_allclose(eng.debug_read("dxi"), dxi, rtol=0, atol=1e-9 * np.abs(dxi).max())
-    assert E1 == pytest.approx(E1o, rel=1e-8)
+    dxi = np.zeros(9 * m); dxi[g.keep] = g.dxi_red
+    np.testing.assert_allclose(eng.debug_read("dxi"), dxi, rtol=0, atol=1e-8 * np.abs(dxi).max())
+    assert E1 == pytest.approx(E1o, rel=1e-6)
     # and the ordinary path is untouched afterwards
     E2, E2o = eng.try_step(1e-4), g.try_step(1e-4)
     assert eng.stats()["counts"]["lu_fallback"] == 1 and E2 == pytest.approx(E2o, rel=1e-9)
