@@ -743,3 +743,32 @@ def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypa
     assert info_d == info_h and info_d["slot_rows"] > 0
     for k in dev:
         np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
+
+
+@pytest.mark.parametrize("n,m,p", [(3, 2, 1.0), (1, 3, 1.0), (7, 4, 1.0), (9, 3, 0.8), (40, 9, 0.5)])
+def test_tiny_scenes_fewer_points_than_point_ranges(n, m, p):
+    """Edge of the slot form's layout: fewer points than its 8 point ranges (empty ranges, waves without a single
+    item, lists of one item), the minimum camera count, a single point -- one trial against the oracle."""
+    sc = make_scene(n, m, vis_p=p)
+    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                          sc.init_R, sc.init_t, axis=sc.axis)
+    g = O.OracleEngine(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    g.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
+    eng = ba._engine
+    assert abs(eng.cost() - g.cost()) <= 1e-12 * g.cost()
+    eng.linearize(); g.linearize()
+    c = 1e-3
+    try:
+        E1o = g.try_step(c)
+    except np.linalg.LinAlgError:  # an under-determined tiny scene: the engine must refuse it too
+        with pytest.raises(np.linalg.LinAlgError):
+            eng.try_step(c)
+        return
+    A, b = g.reduced_system(c)
+    E1 = eng.try_step(c)
+    m9 = 9 * m
+    np.testing.assert_allclose(eng.debug_read("A_full").reshape(m9, m9), A, rtol=0, atol=1e-11 * np.abs(A).max())
+    np.testing.assert_allclose(eng.debug_read("b_full"), b, rtol=0, atol=1e-9 * max(np.abs(b).max(), 1e-300))
+    if np.isfinite(E1o) and np.linalg.cond(g.A) < 1e12:
+        assert E1 == pytest.approx(E1o, rel=1e-6, abs=1e-12)
