@@ -2818,7 +2818,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     int n_cu_dev = 256;
     hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, h->device);
     const int xcd_waves = std::max(1, n_cu_dev / 8) * (160 * 1024 / SLOT_LDS);  // 9 waves of 17,136 B of LDS per CU
-    if (h->schur_mode == SCHUR_SLOTS && (wpr > xcd_waves || (std::max(nobs, N) + 1) * 128LL >= (1LL << 32) || h->force_big))
+    // (below ~4 M items the launch is all prologue and pacing: the unit form's many short waves win -- config 2,
+    // 10k points x 20 cameras: 0.095 against 0.124 ms; equal at 5.5 M items; MVBA_SCHUR=slots keeps the slot form)
+    const bool slots_forced = getenv("MVBA_SCHUR") && !strcmp(getenv("MVBA_SCHUR"), "slots");
+    if (h->schur_mode == SCHUR_SLOTS && (wpr > xcd_waves || (std::max(nobs, N) + 1) * 128LL >= (1LL << 32) || h->force_big ||
+                                         (T < 4000000 && !slots_forced)))
       h->schur_mode = SCHUR_PAIRS;
     const bool slots = h->schur_mode == SCHUR_SLOTS;
     // point ranges.  Unit form: long runs for big problems, but small ones still get ~4096 units of >= 128 items.

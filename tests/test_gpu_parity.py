@@ -729,6 +729,7 @@ def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypa
     sub-lists, bounded-skew merge into step-major rows, pacing table); MVBA_INDEX=host keeps round 2's host
     threads.  The two builds must give the kernel the same arrays, entry for entry."""
     sc = make_scene(n, m, vis_p=p)
+    monkeypatch.setenv("MVBA_SCHUR", "slots")  # (small scenes would take the unit form by default)
 
     def build():
         ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,

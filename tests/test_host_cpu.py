@@ -129,7 +129,7 @@ def test_synthetic_scene_is_consistent_and_shardable():
     np.testing.assert_array_equal(part.pt_ptr, sc.pt_ptr[65000:68001] - o0)
 
 
-def test_bench_cpu_baseline_and_pmc_helpers():
+def test_bench_cpu_baseline_and_pmc_helpers(monkeypatch):
     """bench.py's CPU-side pieces: the oracle-timed baseline returns the contract's fields on a
     tiny sample, and the PMC traffic helper only answers for the workload it was measured on."""
     import json
@@ -142,11 +142,23 @@ def test_bench_cpu_baseline_and_pmc_helpers():
     assert "4000 points" in cb["sample"] and cb["host_cpus"] == os.cpu_count() and cb["rmse_end"] < cb["rmse_start"]
     d = json.load(open(bench.PMC_FILE))
     k1 = d["kernels"]["k_resid_jac"]
+    # the figures are quoted only for the kernel sources they were measured on (sha256 in the file) ...
+    monkeypatch.setattr(bench, "csrc_sha256", lambda: d["csrc_sha256"])
     t, src = bench.pmc_traffic("k_resid_jac", d["n_obs"])
     assert t == pytest.approx((2 * k1["FETCH_SIZE_KiB"] + k1["WRITE_SIZE_KiB"]) * 1024) and "pmc_config3.json" in src
     assert 0.95 < t / (152 * d["n_obs"] + 96 * d["n_points"]) < 1.10  # HBM traffic ~ algorithmic bytes
+    k3 = d["kernels"]["k_schur_slots"]
+    t3, _ = bench.pmc_traffic("k_schur_slots", d["n_obs"])
+    assert t3 == pytest.approx((2 * k3["FETCH_SIZE_KiB"] + k3["WRITE_SIZE_KiB"]) * 1024)
+    assert 1.0 < t3 / (192 * d["n_obs"]) < 1.5  # the slot kernel reads a record once per launch, not 5 times
     assert bench.pmc_traffic("k_resid_jac", d["n_obs"] + 1) == (None, None)
     assert bench.pmc_traffic("no_such_kernel", d["n_obs"]) == (None, None)
+    # ... and dropped, with a note, once the sources have changed
+    monkeypatch.setattr(bench, "csrc_sha256", lambda: "0" * 64)
+    t, src = bench.pmc_traffic("k_resid_jac", d["n_obs"])
+    assert t is None and "STALE" in src
+    monkeypatch.undo()
+    assert len(bench.csrc_sha256()) == 64
 
 
 def test_bench_config1_leg_reproduces_the_reference_counts_on_the_cpu():
