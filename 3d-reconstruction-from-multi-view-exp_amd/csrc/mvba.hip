@@ -604,7 +604,7 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
   constexpr int PB_OFF = LB_OFF + ((SLOTS && DIAG) ? PSTEP * 16 : PSTEP * PROW);
   constexpr int BUFSZ = SLOTS ? PB_OFF + PSTEP * 16 * NPS : PWAVE_LDS;
   static_assert(!SLOTS || BUFSZ <= SLOT_BUF, "slot form: staging buffer larger than the launch provides");
-  int ixk[2][3], ixl[2][3], ixa[2][2];  // two index register sets (the slot form keeps two steps' indices in flight)
+  int ixk[1][3], ixl[1][3], ixa[1][2];  // the next step's indices (the slot form has two pinned register sets of its own)
   auto load_idx = [&](int s0, int (&xk)[3], int (&xl)[3], int (&xa)[2]) {  // indices of the step starting at item s0 (to registers)
     // uniform base + unsigned 32-bit row: the saddr form again (written with int rows the clamps and the
     // address sums were done in 64 bits per lane: ~40 vector instructions per step for seven loads)
@@ -794,17 +794,38 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
                    rowk2 = (unsigned)min(18 + drow, PSTEP - 1) << 2;  // byte offsets of this lane's index rows
     const unsigned rowa0 = (unsigned)min(prow, PSTEP - 1) << 2, rowa1 = (unsigned)min(prow2, PSTEP - 1) << 2;
     const unsigned rowl = (unsigned)min(lane, PSTEP - 1) << 2;
-    auto gld = [](int &dst, unsigned off, const int *base) {
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
-    };
-    auto load_idx_asm = [&](int s0, int (&xk)[3], int (&xl)[3], int (&xa)[2]) {
-      const int *pk = it_k + (beg + s0), *pl = it_l + (beg + s0), *pa = it_a + (beg + s0);  // (wave-uniform: SGPR pairs)
-      gld(xk[0], rowk0, pk); gld(xk[1], rowk1, pk); gld(xk[2], rowk2, pk);
-      if (!DIAG) { gld(xl[0], rowk0, pl); gld(xl[1], rowk1, pl); gld(xl[2], rowk2, pl); }
-      else gld(xl[0], rowl, pk);
-      gld(xa[0], rowa0, pa);
-      if (DIAG) gld(xa[1], rowa1, pa);
-    };
+    // The index registers are PINNED (v152..v167, the top of the 168 a wave has at three waves per SIMD): a value an
+    // asm load "returns" is not there yet, and left to itself the register allocator may copy such a value to
+    // another register between the load and its wait (it did: a v_mov above the counted wait read the register
+    // before the load had landed, and the gather went to an address made of the old contents).  With the variable
+    // bound to one physical register every asm statement finds it in place and nothing is ever copied.
+    register int rk00 asm("v152"), rk01 asm("v153"), rk02 asm("v154"), rl00 asm("v155"), rl01 asm("v156"), rl02 asm("v157"),
+        ra00 asm("v158"), ra01 asm("v159");
+    register int rk10 asm("v160"), rk11 asm("v161"), rk12 asm("v162"), rl10 asm("v163"), rl11 asm("v164"), rl12 asm("v165"),
+        ra10 asm("v166"), ra11 asm("v167");
+    // (clang binds such a variable to its register only where it is NAMED as an asm operand, not through a
+    // reference: hence macros, not lambdas, for the statements that name them)
+#define MVBA_SET0 rk00, rk01, rk02, rl00, rl01, rl02, ra00, ra01
+#define MVBA_SET1 rk10, rk11, rk12, rl10, rl11, rl12, ra10, ra11
+#define MVBA_GLD(dst, off, base) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
+#define MVBA_LOAD_IDX_(s0, K0, K1, K2, L0, L1, L2, A0, A1)                                                              \
+  do {                                                                                                                  \
+    const int *pk = it_k + (beg + (s0)), *pl = it_l + (beg + (s0)), *pa = it_a + (beg + (s0)); /* wave-uniform */       \
+    MVBA_GLD(K0, rowk0, pk); MVBA_GLD(K1, rowk1, pk); MVBA_GLD(K2, rowk2, pk);                                          \
+    if (!DIAG) { MVBA_GLD(L0, rowk0, pl); MVBA_GLD(L1, rowk1, pl); MVBA_GLD(L2, rowk2, pl); }                           \
+    else MVBA_GLD(L0, rowl, pk);                                                                                        \
+    MVBA_GLD(A0, rowa0, pa);                                                                                            \
+    if (DIAG) MVBA_GLD(A1, rowa1, pa);                                                                                  \
+  } while (0)
+#define MVBA_LOAD_IDX(s0, ...) MVBA_LOAD_IDX_(s0, __VA_ARGS__)
+#define MVBA_WAIT_(str, K0, K1, K2, L0, L1, L2, A0, A1)                                                                 \
+  asm volatile(str : "+v"(K0), "+v"(K1), "+v"(K2), "+v"(L0), "+v"(L1), "+v"(L2), "+v"(A0), "+v"(A1)::"memory")
+#define MVBA_WAIT(str, ...) MVBA_WAIT_(str, __VA_ARGS__)
+#define MVBA_WAIT_STEP(...)                                                                                             \
+  do {                                                                                                                  \
+    if (DIAG) MVBA_WAIT("s_waitcnt vmcnt(12)", __VA_ARGS__);                                                            \
+    else MVBA_WAIT("s_waitcnt vmcnt(14)", __VA_ARGS__);                                                                 \
+  } while (0)
     // (32-bit byte offsets only: with 64-bit per-lane addresses this loop needs more than the 168 registers of
     // three waves per SIMD, and a spill's scratch access would be a vector-memory operation the counted waits do
     // not know about -- scenes whose records span 4 GiB run the unit form, mvba_create sees to that)
@@ -814,63 +835,60 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");
     };
     const unsigned ds16 = (unsigned)dslot << 4, ps16 = (unsigned)pslot << 4, ps16b = (unsigned)pslot2 << 4;
-    auto issue_asm = [&](unsigned buf, const int (&xk)[3], const int (&xl)[3], const int (&xa)[2]) {
+    auto issue_asm = [&](unsigned buf, int k0, int k1, int k2, int l0, int l1, int l2, int a0, int a1) {
       const unsigned kb = buf, lb = buf + LB_OFF, pb_ = buf + PB_OFF;
       if (lane < 63) {
-        dma(xk[0], ds16, rec, kb);
-        if (!DIAG) dma(xl[0], ds16, rec, lb);
-        dma(xk[1], ds16, rec, kb + 9 * PROW);
-        if (!DIAG) dma(xl[1], ds16, rec, lb + 9 * PROW);
-        if (!DIAG) dma(xa[0], ps16, PB, pb_);
+        dma(k0, ds16, rec, kb);
+        if (!DIAG) dma(l0, ds16, rec, lb);
+        dma(k1, ds16, rec, kb + 9 * PROW);
+        if (!DIAG) dma(l1, ds16, rec, lb + 9 * PROW);
+        if (!DIAG) dma(a0, ps16, PB, pb_);
       }
       if (lane < 7 * (PSTEP - 18)) {
-        dma(xk[2], ds16, rec, kb + 18 * PROW);
-        if (!DIAG) dma(xl[2], ds16, rec, lb + 18 * PROW);
+        dma(k2, ds16, rec, kb + 18 * PROW);
+        if (!DIAG) dma(l2, ds16, rec, lb + 18 * PROW);
       }
       if (DIAG) {
-        if (lane < PSTEP) dma(xl[0], 7u << 4, rec, lb);
-        dma(xa[0], ps16, PB, pb_);
-        if (lane < 5 * PSTEP - 64) dma(xa[1], ps16b, PB, pb_ + 1024);
+        if (lane < PSTEP) dma(l0, 7u << 4, rec, lb);
+        dma(a0, ps16, PB, pb_);
+        if (lane < 5 * PSTEP - 64) dma(a1, ps16b, PB, pb_ + 1024);
       }
     };
-    auto wait_set = [&](int (&xk)[3], int (&xl)[3], int (&xa)[2], bool all) {
-      if (all)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
-      else if (DIAG)
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
-      else
-        asm volatile("s_waitcnt vmcnt(14)" : "+v"(xk[0]), "+v"(xk[1]), "+v"(xk[2]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xa[0]), "+v"(xa[1])::"memory");
-    };
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {  // (registers the asm operands name must be initialised)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) ixk[u][q] = ixl[u][q] = 0;
-      ixa[u][0] = ixa[u][1] = 0;
-    }
-    load_idx_asm(0, ixk[0], ixl[0], ixa[0]);
-    load_idx_asm(min(PSTEP, last0), ixk[1], ixl[1], ixa[1]);
-    wait_set(ixk[0], ixl[0], ixa[0], true);
-    wait_set(ixk[1], ixl[1], ixa[1], true);
-    issue_asm(lds0, ixk[0], ixl[0], ixa[0]);
-    load_idx_asm(min(2 * PSTEP, last0), ixk[0], ixl[0], ixa[0]);
-    issue_asm(lds0 + BUFSZ, ixk[1], ixl[1], ixa[1]);
-    load_idx_asm(min(3 * PSTEP, last0), ixk[1], ixl[1], ixa[1]);
+    rk00 = rk01 = rk02 = rl00 = rl01 = rl02 = ra00 = ra01 = 0;  // (registers the asm operands name must be initialised)
+    rk10 = rk11 = rk12 = rl10 = rl11 = rl12 = ra10 = ra11 = 0;
+    MVBA_LOAD_IDX(0, MVBA_SET0);
+    MVBA_LOAD_IDX(min(PSTEP, last0), MVBA_SET1);
+    MVBA_WAIT("s_waitcnt vmcnt(0)", MVBA_SET0);
+    MVBA_WAIT("s_waitcnt vmcnt(0)", MVBA_SET1);
+    issue_asm(lds0, MVBA_SET0);
+    MVBA_LOAD_IDX(min(2 * PSTEP, last0), MVBA_SET0);
+    issue_asm(lds0 + BUFSZ, MVBA_SET1);
+    MVBA_LOAD_IDX(min(3 * PSTEP, last0), MVBA_SET1);
     int slot = 0;  // ring position of step s0
-    for (int s0 = 0; s0 < n; s0 += 2 * PSTEP) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {  // (unrolled by two: the index register sets alternate)
-        const int s = s0 + u * PSTEP;
-        if (s < n) {  // (wave-uniform)
-          wait_set(ixk[u], ixl[u], ixa[u], false);  // step s has landed, the indices of step s + 2 are in set u
-          pace_at(s);
-          const int nxt = slot == 0 ? 2 : slot - 1;  // (s + 2) % 3
-          issue_asm(lds0 + nxt * BUFSZ, ixk[u], ixl[u], ixa[u]);
-          load_idx_asm(min(s + 4 * PSTEP, last0), ixk[u], ixl[u], ixa[u]);
-          compute(wbuf + slot * BUFSZ, PSTEP);
-          slot = slot == 2 ? 0 : slot + 1;
-        }
-      }
+    // one step: step s has landed and the indices of step s + 2 are in this set -> gather s + 2, load the indices of s + 4
+#define MVBA_SLOT_STEP(s, ...)                                                                                          \
+  if ((s) < n) { /* wave-uniform */                                                                                     \
+    MVBA_WAIT_STEP(__VA_ARGS__);                                                                                        \
+    pace_at(s);                                                                                                         \
+    const int nxt = slot == 0 ? 2 : slot - 1; /* (s + 2) % 3 */                                                         \
+    issue_asm(lds0 + nxt * BUFSZ, __VA_ARGS__);                                                                         \
+    MVBA_LOAD_IDX(min((s) + 4 * PSTEP, last0), __VA_ARGS__);                                                            \
+    compute(wbuf + slot * BUFSZ, PSTEP);                                                                                \
+    slot = slot == 2 ? 0 : slot + 1;                                                                                    \
+  }
+    for (int s0 = 0; s0 < n; s0 += 2 * PSTEP) {  // (by two: the index register sets alternate)
+      MVBA_SLOT_STEP(s0, MVBA_SET0)
+      MVBA_SLOT_STEP(s0 + PSTEP, MVBA_SET1)
     }
+#undef MVBA_SLOT_STEP
+#undef MVBA_WAIT_STEP
+#undef MVBA_WAIT
+#undef MVBA_WAIT_
+#undef MVBA_LOAD_IDX
+#undef MVBA_LOAD_IDX_
+#undef MVBA_GLD
+#undef MVBA_SET0
+#undef MVBA_SET1
     static_assert(SLOT_OPS == (DIAG ? 12 : 14), "counted wait");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped gathers still in flight land in this wave's LDS
   }

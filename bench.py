@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import contextlib
+import gc
 import io
 import json
 import os
@@ -358,13 +359,21 @@ def main():
     eng.set_profiling(True)
     eng.reset_stats()
     solves0 = eng.n_solves
+    # (as `timeit` does: no cyclic-GC pass inside the timed region -- with torch imported a full collection walks
+    # ~10^6 objects and shows up as one 50-60 ms step in a run of 2.5 ms steps, about once in a hundred steps)
+    gc.collect()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     restarts0 = n_restarts
+    step_end = []
     for _ in range(args.steps):
-        E_ = one_step()
+        E_ = one_step()  # (ends with the cost on the host: the accept / reject decision needs it)
+        step_end.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
+    step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host clock per step: shows a stalled step next to the mean
     st = eng.stats()
     n_solves = eng.n_solves - solves0
     eng.set_profiling(False)
@@ -469,6 +478,8 @@ def main():
             "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_solve": step_bytes, "bytes_per_obs": 824,
                               "achieved": step_bytes / (ms_solve * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": step_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
+                        "argmax": int(step_ms.argmax())},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
         }
         if not args.no_cpu_baseline and world == 1:  # CPU baseline and SVD leg: rank 0 at N = 1 only

@@ -232,3 +232,20 @@ def test_slot_kernel_loops_carry_no_vector_memory_operation_the_counted_waits_do
         straight = [ln for ln in body if ln.startswith(("global_load_lds_dwordx4", "global_load_dword "))]
         straight = [ln for ln in straight if "sc1" not in ln]
         assert len(straight) == n_ops, (count, len(straight))
+    # The index registers an asm load fills are pinned to v152..v167: nothing but those loads (and the zeros
+    # that initialise them) may write one, and no move may read one -- a copy made between a load and its
+    # counted wait reads the register before the data has landed (seen once: the gather went to a stale address).
+    pinned = r"v1(?:5[2-9]|6[0-7])\b"
+    last_wait = max(i for i, ln in enumerate(lines) if ln.startswith(("s_waitcnt vmcnt(12)", "s_waitcnt vmcnt(14)")))
+    for count in ("vmcnt(12)", "vmcnt(14)"):  # prologue + loop of either form (after a loop the compiler's own loads are fine)
+        idx = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt " + count)]
+        start = max([i for i in range(idx[0]) if lines[i].startswith(("global_store", "global_atomic", "s_endpgm"))] or [0])
+        region = lines[start:idx[1]]  # (from the end of whatever wrote results before: the other form's epilogue)
+        idx_loads = [ln for ln in region if ln.startswith("global_load_dword ") and "sc1" not in ln]
+        assert len(idx_loads) >= 24 and all(re.match(r"global_load_dword " + pinned, ln) for ln in idx_loads), idx_loads
+    for ln in lines:
+        w = re.match(r"(\w+)\s+(?:v\[)?" + pinned, ln)
+        if w and not ln.startswith("global_load_dword "):
+            assert re.match(r"v_mov_b32_e32 " + pinned + r", 0$", ln), ln
+        if ln.startswith("v_mov_b32"):
+            assert not re.search(r", " + pinned, ln), ln

@@ -72,6 +72,34 @@ __global__ __launch_bounds__(256) void k_dma(const double2 *__restrict__ tab, co
   if (acc == 1.2345) sink[0] = acc;
 }
 
+// mode R: LDS-DMA with LPR lanes per row (LPR x 16 bytes out of one line per request): 8 = whole lines, 7 = the Schur
+// kernel's 112-byte records, 4 = a 64-byte half line (what compact records would ask for), 3 = a 48-byte point row
+template <int LPR, int UN, int DUP = 1>  // DUP: every index is used by DUP adjacent rows of an instruction (do equal lines coalesce?)
+__global__ __launch_bounds__(256) void k_dma_rows(const double2 *__restrict__ tab, const int *__restrict__ idx, long long n,
+                                                  double *sink) {
+  extern __shared__ double2 lds[];  // [waves][UN][64]
+  constexpr int RPI = 64 / LPR;     // rows per instruction
+  const int lane = threadIdx.x & 63, g = lane / LPR, s = lane - LPR * g, w = threadIdx.x >> 6;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  double2 *mine = lds + (size_t)w * UN * 64;
+  double acc = 0.0;
+  for (long long base = wave * (RPI * UN); base + RPI * UN <= n; base += nwaves * (RPI * UN)) {
+    int ii[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) ii[u] = idx[base + RPI * u + min(g, RPI - 1) / DUP * DUP];
+    if (lane < LPR * RPI) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        __builtin_amdgcn_global_load_lds(tab + (size_t)ii[u] * 8 + s, mine + u * 64, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc += mine[lane].x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (acc == 1.2345) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
   const long long n_idx = 1LL << 24;  // 16.8M lines gathered per launch = 2.1 GB of lines
   double *sink; CK(hipMalloc(&sink, 64));
@@ -111,6 +139,15 @@ int main(int argc, char **argv) {
       timeit(nm, [&] { hipLaunchKernelGGL(k_coop<8>, dim3(grid), dim3(256), 0, 0, tab, d_idx, n_idx, sink); }, 128.0);
       snprintf(nm, sizeof nm, "D lds-dma UN=4    %2d w/CU", bpc * 4);
       timeit(nm, [&] { hipLaunchKernelGGL(k_dma<4>, dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 128.0);
+      if (bpc == 4 && t == 0) {  // request size against request rate, from L2
+        timeit("R lds-dma 8 lanes/row 128B", [&] { hipLaunchKernelGGL((k_dma_rows<8, 4>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 128.0);
+        timeit("R lds-dma 7 lanes/row 112B", [&] { hipLaunchKernelGGL((k_dma_rows<7, 4>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 112.0);
+        timeit("R 7 lanes/row, rows in equal PAIRS", [&] { hipLaunchKernelGGL((k_dma_rows<7, 4, 2>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 112.0);
+        timeit("R 7 lanes/row, rows in equal TRIPLES", [&] { hipLaunchKernelGGL((k_dma_rows<7, 4, 3>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 112.0);
+        timeit("R lds-dma 4 lanes/row  64B", [&] { hipLaunchKernelGGL((k_dma_rows<4, 4>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 64.0);
+        timeit("R lds-dma 3 lanes/row  48B", [&] { hipLaunchKernelGGL((k_dma_rows<3, 4>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 48.0);
+        timeit("R lds-dma 2 lanes/row  32B", [&] { hipLaunchKernelGGL((k_dma_rows<2, 4>), dim3(grid), dim3(256), 4 * 4 * 1024, 0, tab, d_idx, n_idx, sink); }, 32.0);
+      }
       if (bpc == 4) {
         snprintf(nm, sizeof nm, "D lds-dma UN=8    %2d w/CU", bpc * 4);
         timeit(nm, [&] { hipLaunchKernelGGL(k_dma<8>, dim3(grid), dim3(256), 4 * 8 * 1024, 0, tab, d_idx, n_idx, sink); }, 128.0);
