@@ -2269,27 +2269,39 @@ constexpr int IDX_WAVES = 4;  // waves per block of the counting / filling kerne
 
 __device__ __forceinline__ int idx_pair_id(int k, int l, int m) { return k * m - k * (k - 1) / 2 + (l - k); }
 
-// hist[w][q] = items of pair q among the points of wave w's chunk
+// hist[w][q] = items of pair q among the points of wave w's chunk.
+// GLOBAL: the pair histogram does not fit LDS (more than ~138 cameras: 125 k pairs at 500) -- the wave counts in its
+// own row of `hist` in device memory instead (zeroed by the caller).  Same walk, same ranks; a row visit is then a
+// dependent round trip to L2 (agent-scope accesses: a later visit of the same pair, possibly from another lane of
+// this wave, must see the count), ~1-2 us per (point, first camera) row instead of ~0.1.
+template <bool GLOBAL>
 __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_count(long long N, int m, int P, const long long *__restrict__ pt_ptr,
                                                               const int *__restrict__ cam_idx, int chunk,
                                                               int *__restrict__ hist) {
   extern __shared__ int s_hist_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int *s_hist = s_hist_all + (size_t)wv * P;
   const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
-  for (int q = lane; q < P; q += 64) s_hist[q] = 0;
-  wave_sync();
+  int *s_hist = GLOBAL ? hist + (size_t)w * P : s_hist_all + (size_t)wv * P;
+  if (!GLOBAL) {
+    for (int q = lane; q < P; q += 64) s_hist[q] = 0;
+    wave_sync();
+  }
   const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
   for (long long a = a0; a < a1; ++a) {
     const long long o0 = pt_ptr[a];
     const int d = (int)(pt_ptr[a + 1] - o0);
     for (int i = 0; i < d; ++i) {
       const int k = cam_idx[o0 + i];
-      for (int j = i + lane; j < d; j += 64) s_hist[idx_pair_id(k, cam_idx[o0 + j], m)] += 1;  // distinct pairs per instruction
+      for (int j = i + lane; j < d; j += 64) {  // distinct pairs per instruction
+        int *c = s_hist + idx_pair_id(k, cam_idx[o0 + j], m);
+        if (GLOBAL) __hip_atomic_store(c, __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *c += 1;
+      }
       wave_sync();
     }
   }
-  for (int q = lane; q < P; q += 64) hist[(size_t)w * P + q] = s_hist[q];
+  if (!GLOBAL)
+    for (int q = lane; q < P; q += 64) hist[(size_t)w * P + q] = s_hist[q];
 }
 
 // exclusive prefix over the waves, per pair (in place); cnt[q] = total
@@ -2306,17 +2318,21 @@ __global__ void k_idx_scan(int P, int n_waves, int *__restrict__ hist, long long
 }
 
 // the same walk again: item r of pair q goes to sub-list r % S[q], position r / S[q] (the host's dealing)
+// (GLOBAL: the running ranks live in the wave's row of `hist` itself, which the scan has turned into start ranks)
+template <bool GLOBAL>
 __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m, int P, const long long *__restrict__ pt_ptr,
                                                              const int *__restrict__ cam_idx, int chunk,
-                                                             const int *__restrict__ hist, const int *__restrict__ S,
+                                                             int *__restrict__ hist, const int *__restrict__ S,
                                                              const int *__restrict__ vp_ptr, const long long *__restrict__ vp_off,
                                                              int *__restrict__ it_k, int *__restrict__ it_l, int *__restrict__ it_a) {
   extern __shared__ int s_hist_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int *s_rank = s_hist_all + (size_t)wv * P;
   const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
-  for (int q = lane; q < P; q += 64) s_rank[q] = hist[(size_t)w * P + q];  // items of earlier waves
-  wave_sync();
+  int *s_rank = GLOBAL ? hist + (size_t)w * P : s_hist_all + (size_t)wv * P;
+  if (!GLOBAL) {
+    for (int q = lane; q < P; q += 64) s_rank[q] = hist[(size_t)w * P + q];  // items of earlier waves
+    wave_sync();
+  }
   const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
   for (long long a = a0; a < a1; ++a) {
     const long long o0 = pt_ptr[a];
@@ -2325,8 +2341,14 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m,
       const int k = cam_idx[o0 + i];
       for (int j = i + lane; j < d; j += 64) {
         const int q = idx_pair_id(k, cam_idx[o0 + j], m);
-        const int r = s_rank[q];
-        s_rank[q] = r + 1;
+        int r;
+        if (GLOBAL) {
+          r = __hip_atomic_load(s_rank + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(s_rank + q, r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          r = s_rank[q];
+          s_rank[q] = r + 1;
+        }
         const int sq = S[q];
         const long long pos = vp_off[vp_ptr[q] + (r % sq)] + r / sq;
         it_k[pos] = (int)(o0 + i);
@@ -2440,7 +2462,7 @@ struct mvba_handle {
   bool slot_pace = true;
   int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
   int *d_seg_end = nullptr, *d_prog = nullptr;
-  bool index_on_device = false;       // the slot form's index was built by the k_idx_* kernels (nothing to upload)
+  bool index_on_device = false;       // the Schur index was built by the k_idx_* kernels (nothing to upload)
   long long *d_trace = nullptr;       // -DMVBA_SLOT_TRACE builds with MVBA_SLOT_TRACE=<file>: per-wave timings of the last launch
   int4 *d_wdesc = nullptr;
   int *d_wunits = nullptr;
@@ -2775,22 +2797,30 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       body(0);
       for (auto &x : th) x.join();
     };
-    // The index is built on the DEVICE (k_idx_*) when a wave's pair histogram fits LDS (P ints x 4 waves per block:
-    // up to ~138 cameras) and the slot form will use it; MVBA_INDEX=host keeps the host threads (the test that the
-    // two builds are identical).  The unit form of larger camera counts is still sorted on the host.
-    bool dev_build = (size_t)P * sizeof(int) * IDX_WAVES <= 150 * 1024 && N > 0 && nobs > 0 &&
-                     !(getenv("MVBA_INDEX") && !strcmp(getenv("MVBA_INDEX"), "host"));
-    const int idx_chunk = (int)std::max<long long>(32, (N + 4095) / 4096);           // points per wave
+    // The index is built on the DEVICE (k_idx_*): a stable counting sort by pair, every wave walking its own chunk of
+    // points with a private pair histogram -- in LDS when P ints x 4 waves per block fit (up to ~138 cameras), else in
+    // the wave's own row of a device buffer (at most 2 GiB of rows: 4096 waves at 500 cameras).  MVBA_INDEX=host keeps
+    // the host threads, MVBA_INDEX=global forces the device-memory histogram (the tests that the builds are identical).
+    const char *idx_env = getenv("MVBA_INDEX");
+    const bool hist_lds = (size_t)P * sizeof(int) * IDX_WAVES <= 150 * 1024 && !(idx_env && !strcmp(idx_env, "global"));
+    bool dev_build = N > 0 && nobs > 0 && !(idx_env && !strcmp(idx_env, "host"));
+    const long long max_idx_waves = hist_lds ? 4096 : std::max<long long>(IDX_WAVES, std::min<long long>(4096, (2LL << 30) / (4 * P)));
+    const int idx_chunk = (int)std::max<long long>(32, (N + max_idx_waves - 1) / max_idx_waves);  // points per wave
     const long long idx_waves = dev_build ? ((N + idx_chunk - 1) / idx_chunk + IDX_WAVES - 1) / IDX_WAVES * IDX_WAVES : 0;
+    const size_t idx_lds = hist_lds ? P * sizeof(int) * IDX_WAVES : 0;
     int *d_hist = nullptr;
     long long *d_cnt = nullptr;
     if (dev_build) {
       TRY(dmalloc(&d_hist, (size_t)idx_waves * P));
       TRY(dmalloc(&d_cnt, (size_t)P));
-      TRYH(hipFuncSetAttribute((const void *)k_idx_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P * sizeof(int) * IDX_WAVES)));
-      TRYH(hipFuncSetAttribute((const void *)k_idx_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P * sizeof(int) * IDX_WAVES)));
-      hipLaunchKernelGGL(k_idx_count, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), P * sizeof(int) * IDX_WAVES, h->stream, N, m,
-                         (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist);
+      if (hist_lds) {
+        TRYH(hipFuncSetAttribute((const void *)k_idx_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)idx_lds));
+        TRYH(hipFuncSetAttribute((const void *)k_idx_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)idx_lds));
+      } else {
+        TRYH(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)idx_waves * P, h->stream));
+      }
+      hipLaunchKernelGGL(hist_lds ? k_idx_count<false> : k_idx_count<true>, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), idx_lds,
+                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist);
       hipLaunchKernelGGL(k_idx_scan, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, h->stream, (int)P, (int)idx_waves, d_hist, d_cnt);
       TRYH(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(long long) * P, hipMemcpyDeviceToHost, h->stream));
       TRYH(hipStreamSynchronize(h->stream));
@@ -2871,7 +2901,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       for (int sI = 0; sI < S[q]; ++sI) vp_off[vp_ptr[q] + sI + 1] = (cnt[q] - sI + S[q] - 1) / S[q];
     for (int v = 0; v < VP; ++v) vp_off[v + 1] += vp_off[v];
     // the window-equalised merge (MVBA_SLOT_WINDOW, an experiment) exists on the host only
-    const bool dev_items = dev_build && slots && h->slot_window >= (1LL << 39);
+    const bool dev_items = dev_build && (!slots || h->slot_window >= (1LL << 39));
     int *d_pk = nullptr, *d_pl = nullptr, *d_pa = nullptr, *d_S = nullptr, *d_vp_ptr = nullptr;
     long long *d_vp_off = nullptr;
     auto free_dev_tmp = [&]() {
@@ -2885,8 +2915,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       TRYH(hipMemcpyAsync(d_S, S.data(), sizeof(int) * P, hipMemcpyHostToDevice, h->stream));
       TRYH(hipMemcpyAsync(d_vp_ptr, vp_ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
       TRYH(hipMemcpyAsync(d_vp_off, vp_off.data(), sizeof(long long) * (VP + 1), hipMemcpyHostToDevice, h->stream));
-      hipLaunchKernelGGL(k_idx_fill, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), P * sizeof(int) * IDX_WAVES, h->stream, N, m,
-                         (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_S, d_vp_ptr, d_vp_off, d_pk, d_pl, d_pa);
+      hipLaunchKernelGGL(hist_lds ? k_idx_fill<false> : k_idx_fill<true>, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), idx_lds,
+                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_S, d_vp_ptr, d_vp_off, d_pk, d_pl, d_pa);
       TRYH(hipGetLastError());
     } else {
       if (dev_build) { hipFree(d_hist); hipFree(d_cnt); d_hist = nullptr; d_cnt = nullptr; }
@@ -3155,6 +3185,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       }
       q_ptr[x + 1] = (int)q_units.size();
     }
+    if (dev_items) {  // the pair-major arrays stay where the fill kernel wrote them
+      h->d_it_k = d_pk; h->d_it_l = d_pl; h->d_it_a = d_pa;
+      d_pk = d_pl = d_pa = nullptr;
+      free_dev_tmp();
+      h->index_on_device = true;
+    }
     }
     h->n_items = T;
     h->n_items_offdiag = T - Tdiag;
@@ -3230,6 +3266,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       TRYH(hipMemcpy(h->d_it_k, it_k.data(), sizeof(int) * it_k.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_l, it_l.data(), sizeof(int) * it_l.size(), hipMemcpyHostToDevice));
       TRYH(hipMemcpy(h->d_it_a, it_a.data(), sizeof(int) * it_a.size(), hipMemcpyHostToDevice));
+    }
+    if (!it_k.empty() || h->index_on_device) {
       if (h->schur_mode == SCHUR_PAIRS) {
         std::vector<int4> qdesc(units.size());  // descriptors in queue order (the kernel indexes both arrays by queue position)
         for (size_t i = 0; i < q_units.size(); ++i) qdesc[i] = units[q_units[i]];

@@ -746,6 +746,39 @@ def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypa
         np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
 
 
+@pytest.mark.parametrize("n,m,p,hist", [(6000, 24, 0.4, "lds"), (6000, 24, 0.4, "global"), (3000, 160, 0.08, "auto"),
+                                        (500, 5, 1.0, "global"), (2, 2, 1.0, "global")])
+def test_unit_form_index_built_on_the_device_is_the_host_built_one(n, m, p, hist, monkeypatch):
+    """The unit form's pair-major index (beyond 100 cameras, small scenes, scenes of 4 GiB of records) comes out of
+    the same kernels: with the wave's pair histogram in LDS, or -- from ~138 cameras on -- in the wave's row of a
+    device buffer (MVBA_INDEX=global forces that at any size).  Entry for entry what MVBA_INDEX=host builds, and
+    one trial on it equals the trial on the host-built index bit for bit."""
+    sc = make_scene(n, m, vis_p=p)
+    monkeypatch.setenv("MVBA_SCHUR", "pairs")
+
+    def build():
+        ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                              sc.init_R, sc.init_t, axis=sc.axis)
+        eng = ba._engine
+        assert eng.schur_info()["kernel"] == "pairs"
+        idx = {k: eng.debug_read(k) for k in ("index_k", "index_l", "index_a")}
+        eng.cost(); eng.linearize()
+        E1 = eng.try_step(1e-3)
+        return idx, eng.schur_info(), E1, eng.debug_read("A_full"), eng.debug_read("dxi")
+
+    if hist == "global":
+        monkeypatch.setenv("MVBA_INDEX", "global")
+    dev, info_d, E_d, A_d, dxi_d = build()
+    monkeypatch.setenv("MVBA_INDEX", "host")
+    host, info_h, E_h, A_h, dxi_h = build()
+    assert info_d == info_h and dev["index_k"].size > 0
+    for k in dev:
+        np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
+    assert E_d == E_h
+    np.testing.assert_array_equal(A_d, A_h)
+    np.testing.assert_array_equal(dxi_d, dxi_h)
+
+
 @pytest.mark.parametrize("n,m,p", [(3, 2, 1.0), (1, 3, 1.0), (7, 4, 1.0), (9, 3, 0.8), (40, 9, 0.5)])
 def test_tiny_scenes_fewer_points_than_point_ranges(n, m, p):
     """Edge of the slot form's layout: fewer points than its 8 point ranges (empty ranges, waves without a single
