@@ -3652,6 +3652,18 @@ int mvba_snapshot_read(mvba_handle *h, int64_t i, double *X, double *f, double *
   return MVBA_OK;
 }
 
+int mvba_snapshot_restore(mvba_handle *h, int64_t i) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  if (i < 0 || i >= h->n_snap) return fail(MVBA_ERR_BADARG, "no such log entry");
+  MVBA_HIP(hipSetDevice(h->device));
+  const double *src = h->snap_slabs[(size_t)(i / SNAP_SLAB)] + snap_stride(h) * (size_t)(i % SNAP_SLAB);
+  // what mvba_set_params does, from device memory: the committed state is replaced, linearisation and trial are void
+  MVBA_HIP(hipMemcpyAsync(h->d_X[h->cur], src, sizeof(double) * 3 * h->N, hipMemcpyDeviceToDevice, h->stream));
+  MVBA_HIP(hipMemcpyAsync(h->d_cam15[h->cur], src + 3 * h->N, sizeof(double) * CAM_IN * h->m, hipMemcpyDeviceToDevice, h->stream));
+  h->have_params = true; h->linearized = false; h->have_trial = false;
+  return MVBA_OK;
+}
+
 int mvba_snapshot_clear(mvba_handle *h) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   h->n_snap = 0;  // (the slabs stay for the next run; mvba_destroy frees them)

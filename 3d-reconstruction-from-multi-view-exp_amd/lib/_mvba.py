@@ -51,6 +51,7 @@ SIGNATURES = {
     "mvba_snapshot_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mvba_snapshot_read": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp]),
     "mvba_snapshot_clear": (C.c_int, [C.c_void_p]),
+    "mvba_snapshot_restore": (C.c_int, [C.c_void_p, C.c_int64]),
     "mvba_cost": (C.c_int, [C.c_void_p, _dp]),
     "mvba_linearize": (C.c_int, [C.c_void_p]),
     "mvba_try_step": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -182,6 +183,10 @@ class HipEngine:
 
     def snapshot_clear(self):
         raise_for(self.lib.mvba_snapshot_clear(self._h), self.lib)
+
+    def snapshot_restore(self, i):
+        """Log entry i becomes the committed state again (set_params from device memory)."""
+        raise_for(self.lib.mvba_snapshot_restore(self._h, int(i)), self.lib)
 
     def apply_similarity(self, R0, t0, scale):
         """Committed state -> scale * X R0^T + t0 (likewise t), R0 R, on the device (ref :242-258)."""

@@ -336,10 +336,12 @@ def main():
     # tolerance.  On this scene the first 12 outer iterations accept their first trial; after that
     # the optimisation has converged to the noise floor and most iterations need two solves.  So that
     # `value` does not depend on where K falls, an episode is cut at EPISODE iterations and the next
-    # one starts from the same initial state (a host->device set_params + one cost pass, inside the
-    # timed region).  The default W + K = 12 never restarts.
+    # one starts from the same initial state (mvba_snapshot_restore of the device-resident initial state +
+    # one cost pass, inside the timed region).  The default W + K = 12 never restarts.
     EPISODE = 12
     state0 = eng.get_params()
+    eng.snapshot_clear()
+    eng.snapshot()  # the initial state, kept in device memory: an episode restart is a device-to-device copy
     lm = LevenbergMarquardt(eng, 2.0)
     E0 = lm.E
     n_restarts = 0
@@ -347,7 +349,7 @@ def main():
     def one_step():
         nonlocal lm, n_restarts
         if lm.count == EPISODE:
-            eng.set_params(*state0)
+            eng.snapshot_restore(0)
             lm = LevenbergMarquardt(eng, 2.0)
             n_restarts += 1
         E_, _d = lm.iterate()

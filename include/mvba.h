@@ -106,11 +106,13 @@ int mvba_commit(mvba_handle *h);
  * a log kept in device memory -- one device-to-device copy on the engine's stream, nothing crosses PCIe and the
  * host does not wait; mvba_snapshot_read fetches entry i (what get_log() does, once, afterwards);
  * mvba_snapshot_clear empties the log (the reference clears it at the start of every optimize, :90) and keeps
- * its memory for the next run. */
+ * its memory for the next run; mvba_snapshot_restore makes entry i the committed state again (mvba_set_params
+ * from device memory: linearisation and trial become void; nothing crosses PCIe). */
 int mvba_snapshot(mvba_handle *h);
 int mvba_snapshot_count(mvba_handle *h, int64_t *n);
 int mvba_snapshot_read(mvba_handle *h, int64_t i, double *X, double *f, double *u, double *t, double *R);
 int mvba_snapshot_clear(mvba_handle *h);
+int mvba_snapshot_restore(mvba_handle *h, int64_t i);
 
 /* Per-kernel device timing; off by default. */
 int mvba_set_profiling(mvba_handle *h, int32_t enabled);

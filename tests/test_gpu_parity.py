@@ -746,6 +746,31 @@ def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypa
         np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
 
 
+def test_snapshot_restore_brings_back_a_logged_state():
+    """mvba_snapshot_restore = set_params from the device-resident log: after some LM steps, restoring entry 0
+    gives the initial cost and the initial parameters again, bit for bit, and the next trial is the first one's."""
+    sc = make_scene(3000, 12, vis_p=0.5)
+    ba = BundleAdjuster.from_observations(sc.n_points, 12, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                          sc.init_R, sc.init_t, axis=sc.axis)
+    eng = ba._engine
+    p0 = eng.get_params()
+    E0 = eng.cost()
+    eng.snapshot_clear(); eng.snapshot()
+    eng.linearize(); E1 = eng.try_step(1e-3); eng.commit()
+    eng.linearize(); eng.try_step(1e-4); eng.commit()
+    assert eng.cost() < E0
+    with pytest.raises((ValueError, RuntimeError)):
+        eng.snapshot_restore(5)
+    eng.snapshot_restore(0)
+    with pytest.raises(RuntimeError):  # the linearisation went with the state it belonged to
+        eng.try_step(1e-3)
+    assert eng.cost() == E0
+    for a, b in zip(eng.get_params(), p0):
+        np.testing.assert_array_equal(a, b)
+    eng.linearize()
+    assert eng.try_step(1e-3) == E1
+
+
 @pytest.mark.parametrize("n,m,p,hist", [(6000, 24, 0.4, "lds"), (6000, 24, 0.4, "global"), (3000, 160, 0.08, "auto"),
                                         (500, 5, 1.0, "global"), (2, 2, 1.0, "global")])
 def test_unit_form_index_built_on_the_device_is_the_host_built_one(n, m, p, hist, monkeypatch):
