@@ -285,6 +285,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     host_transport = args.transport == "host"
+    if not host_transport and local_rank >= max(torch.cuda.device_count(), 1):
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({torch.cuda.device_count()} visible) and RCCL "
+                         "refuses two ranks on one device; `--transport host` rehearses the N > 1 path with ranks sharing GPUs")
     device = local_rank % max(torch.cuda.device_count(), 1) if host_transport else local_rank
     torch.cuda.set_device(device)
     # MVBA_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, communicator inside
