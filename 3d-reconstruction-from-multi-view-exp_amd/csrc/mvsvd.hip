@@ -374,95 +374,160 @@ __global__ __launch_bounds__(1024) void k_jacobi(double *__restrict__ Ag, double
   }
 }
 
-// n <= 32: both matrices in LDS, 256 threads, no divides or square roots on the serial path
-// (v_rcp_f64 / v_rsq_f64 seeds + Newton steps to full precision), and the two-sided update
-// A <- J^T A J in a single pass from the old A:
-//   A'[i][j] = c_i c_j A[i][j] + c_i t_j A[i][pj] + t_i c_j A[pi][j] + t_i t_j A[pi][pj]
-// with pi = partner of index i in this step's pairing and (c_i, t_i) its rotation coefficients
-// (t = -s for the smaller index of a pair, +s for the larger; c = 1, t = 0, pi = i if unpaired).
-// Thread = (row group i0 = tid >> 5, column j = tid & 31), rows i = i0 + 8u.  Measured at n = 24:
-// 4570 cycles per step on one wave (LDS-instruction bound), ~1200 with the work on 4 waves.
-__device__ __forceinline__ double rcp_nr(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  return y * (2.0 - x * y);
-}
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y * (1.5 - 0.5 * x * y * y);
+// n <= 32: the small eigen-solver (one workgroup, both matrices in LDS, cyclic Jacobi in the round-robin order).
+// A step took 0.8-1 us however it was arranged in round 2 (two or four barriers, pipelined or not) and in the first
+// attempts of round 3 (bank-conflict-free layouts, one barrier, every thread computing its own rotations): what a step
+// costs is the number of INSTRUCTIONS a wave executes in it -- ~300 with the roles derived inside the step loop (two
+// integer divisions by the runtime order, the pairing looked up or computed, address arithmetic) -- times the waves per
+// SIMD.  So (0.79 -> 0.45 us per step, 0.17 -> 0.10 ms at 24 columns):
+//  * the pairing never changes -- pairs are always the indices (2I, 2I + 1); what changes is where the data sits: a step
+//    writes its results to the positions the tournament's rotation assigns them (player 0 stays, the others move one
+//    seat on), into the OTHER of two buffers.  A thread's role and all its addresses are computed once, before the loops;
+//  * a thread owns what it updates: the pairs cut A into 2 x 2 blocks (rows of pair I, columns of pair J) and V into
+//    1 x 2 pieces, and a piece's new values depend on its old ones and the two rotations alone (before: every thread
+//    read four old values per element it wrote, and a barrier separated reading from writing);
+//  * two phases per step: `half` threads turn the pivot blocks into (c, s) -- out of two reciprocal square roots: with
+//    d = a_qq - a_pp, b = 2 a_pq, 1/r = rsq(d^2 + b^2): cos 2θ = |d| / r, cos^2 θ = (1 + cos 2θ) / 2, 1/cos θ = rsq(cos^2 θ),
+//    sin θ = |b| / (2 r cos θ) with the sign of b d (the inner rotation, |θ| <= π/4); one Newton step per rsq (v_rsq_f64
+//    alone is good to 5e-8, one step to 4e-15: tools/microbench/rsq_accuracy.hip) and one step of re-normalisation
+//    (c, s) *= 1.5 - 0.5 (c^2 + s^2), which squares what is left: orthogonal to 1e-28, the angle good to 1e-14 (an angle
+//    error only slows convergence, quadratically little) -- barrier, everybody applies them, barrier.  (Every thread
+//    computing its rotations itself saves a barrier and costs 30 instructions per rotation on twelve waves: 0.50 us.)
+//  * convergence is tested directly after each sweep (every block thread looks at its four elements) instead of by a
+//    whole sweep that finds nothing to rotate.
+// The phantom index of an odd order is a zero row / column: its pivot a_pq is 0, so it is never rotated, wherever it sits.
+// After a sweep (np - 1 steps) every index is back in its seat.
+constexpr int JW = 32, JWS = JW + 1;  // max order and padded LDS stride of the small solver
+constexpr int JT = 768;               // its threads
+
+// Is a_pq worth a rotation?  Above the relative threshold tol sqrt(a_pp a_qq) (small eigenvalues keep their RELATIVE
+// accuracy) -- and above the rounding noise of the update itself, 2 eps max(a_pp, a_qq): between a large and a small
+// eigenvalue (1e9 and 0.2 in a rank-4 measurement matrix with noise) the relative threshold 1e-11 sits AT that noise
+// (1.4e-7 against ~1e-7), such pairs flicker above it for ever, and a value of that size moves the eigenvalues by
+// a_pq^2 / (λ_p - λ_q) ~ 1e-23 and the vectors by 1e-16.
+__device__ __forceinline__ bool jacobi_needs(double app, double apq, double aqq, double tol2) {
+  const double big = fmax(fabs(app), fabs(aqq)) * 4.5e-16;
+  return apq * apq > fmax(tol2 * fabs(app * aqq), big * big);
 }
 
-constexpr int JW = 32, JWS = JW + 1;  // max order and padded LDS stride of the small solver
-__global__ __launch_bounds__(256) void k_jacobi_small(double *__restrict__ Ag, double *__restrict__ Vg, int n, int max_sweeps,
-                                                     double tol, int *__restrict__ sweeps_done) {
-  __shared__ double A[JW * JWS], V[JW * JWS], cc[JW], tt[JW];
-  __shared__ int pn[JW];
-  __shared__ int s_rot;
+// (c, s) that annihilate a_pq; false = the pair is left alone
+__device__ __forceinline__ bool jacobi_rotation(double app, double apq, double aqq, double tol2, double &c, double &sn) {
+  c = 1.0; sn = 0.0;
+  if (!jacobi_needs(app, apq, aqq, tol2)) return false;
+  const double d = aqq - app, b = 2.0 * apq;
+  const double u = fma(d, d, b * b);
+  double ir = __builtin_amdgcn_rsq(u);
+  ir = ir * fma(-0.5 * u * ir, ir, 1.5);
+  const double c2 = fma(0.5 * fabs(d), ir, 0.5);
+  double ic = __builtin_amdgcn_rsq(c2);
+  ic = ic * fma(-0.5 * c2 * ic, ic, 1.5);
+  c = c2 * ic;
+  sn = copysign(0.5 * fabs(b) * ir * ic, d == 0.0 ? b : b * d);  // (τ = 0: θ = π/4 with the sign of a_pq)
+  const double f = fma(-0.5, fma(c, c, sn * sn), 1.5);
+  c *= f; sn *= f;
+  return true;
+}
+
+// LDS layout: A BLOCK-major, [row pair I][column pair J][2 x 2] with 16 blocks per block row, so a thread's block is 32
+// contiguous bytes (two 16-byte loads, consecutive threads consecutive blocks); V row-major with stride 33, its threads
+// running over the ROWS of one column pair (banks 2 i: conflict-free).
+constexpr int JHB = JW / 2;  // block rows / columns of the block-major A
+__device__ __forceinline__ int jblk(int r, int c) { return (((r >> 1) * JHB + (c >> 1)) << 2) + ((r & 1) << 1) + (c & 1); }
+
+// Threads 0..255 own an A block (I = t >> 4, J = t & 15), threads 256.. a V piece (J = v >> 5, row i = v & 31); the launch
+// brings 256 + 32 half threads.
+__global__ __launch_bounds__(JT) void k_jacobi_small(double *__restrict__ Ag, double *__restrict__ Vg, int n, int max_sweeps,
+                                                    double tol, int *__restrict__ sweeps_done) {
+  __shared__ __attribute__((aligned(16))) double Ab[2][JHB * JHB * 4];
+  __shared__ double Vb[2][JW * JWS];
+  __shared__ double2 rot[JHB];  // (c, s) of this step's pairs
+  __shared__ int s_rot[2];  // "a pair is still above the threshold" after the even / odd sweeps
   const int tid = threadIdx.x;
   const int np = (n + 1) & ~1, half = np / 2;
-  for (int e = tid; e < JW * JW; e += 256) {
+  for (int e = tid; e < JW * JW; e += (int)blockDim.x) {
     const int i = e / JW, j = e % JW;
-    A[i * JWS + j] = (i < n && j < n) ? Ag[(size_t)i * n + j] : 0.0;
-    V[i * JWS + j] = (i == j) ? 1.0 : 0.0;
+    Ab[0][jblk(i, j)] = (i < n && j < n) ? Ag[(size_t)i * n + j] : 0.0;  // (the phantom row / column of an odd order: zeros)
+    Vb[0][i * JWS + j] = (i == j) ? 1.0 : 0.0;
   }
-  if (tid == 0) s_rot = 0;
+  if (tid == 0) s_rot[0] = s_rot[1] = 0;
   __syncthreads();
-  const int j = tid & 31, i0 = tid >> 5;
+  // where the data at index x sits after a step: seats T[k] = 2k (top row), B[k] = 2k + 1 (bottom row), pairs (T[k], B[k]);
+  // T[0] stays, B[0] -> T[1], T[k] -> T[k+1], T[half-1] -> B[half-1], B[k] -> B[k-1]
+  auto seat = [&](int x) {
+    if (x == 0 || half == 1) return x;
+    if (x & 1) return x == 1 ? 2 : x - 2;
+    return x == np - 2 ? np - 1 : x + 2;
+  };
+  const bool a_role = tid < JHB * JHB;
+  // (A: the thread of a block BELOW the diagonal computes its mirror image above it -- the same inputs through the
+  // same operations -- and writes the transposed result, so that A stays EXACTLY symmetric.  Computed independently,
+  // the two copies of an element pick up different rounding (1e-10 absolute next to eigenvalues of 1e6), the seats
+  // swap which copy a pivot reads, and a pair whose one copy is below the threshold and the other above it is then
+  // never rotated and never accepted.)
+  const int tI = tid >> 4, tJ = tid & (JHB - 1);
+  const bool lower = a_role && tI > tJ, diag = a_role && tI == tJ;
+  const int I = a_role ? min(tI, tJ) : 0, J = a_role ? max(tI, tJ) : (tid - JHB * JHB) >> 5, row = (tid - JHB * JHB) & (JW - 1);
+  const bool active = a_role ? (tI < half && tJ < half) : (J < half && row < n);
+  const int in0 = a_role ? (I * JHB + J) << 2 : row * JWS + 2 * J;  // the 2 x 2 block of A / the pair of V entries (adjacent)
+  const int Pi = seat(2 * I), Qi = seat(2 * I + 1), Pj = seat(2 * J), Qj = seat(2 * J + 1);
+  // where the four new values go: (Pi,Pj) (Pi,Qj) (Qi,Pj) (Qi,Qj), transposed for a thread below the diagonal
+  const int o0 = a_role ? (lower ? jblk(Pj, Pi) : jblk(Pi, Pj)) : row * JWS + Pj;
+  const int o1 = a_role ? (lower ? jblk(Qj, Pi) : jblk(Pi, Qj)) : row * JWS + Qj;
+  const int o2 = lower ? jblk(Pj, Qi) : jblk(Qi, Pj), o3 = lower ? jblk(Qj, Qi) : jblk(Qi, Qj);
   const double tol2 = tol * tol;
-  int sweep = 0;
+  int sweep = 0, cur = 0;
   for (; sweep < max_sweeps; ++sweep) {
-    for (int step = 0; step < np - 1; ++step) {
-      if (tid < JW) { cc[tid] = 1.0; tt[tid] = 0.0; pn[tid] = tid; }
+    for (int step = 0; step < np - 1; ++step, cur ^= 1) {
+      const double *A = Ab[cur], *V = Vb[cur];
+      double *An = Ab[cur ^ 1], *Vn = Vb[cur ^ 1];
+      if (tid < half) {  // the rotation of pair `tid` from its pivot block
+        const int pv = (tid * JHB + tid) << 2;
+        const double2 p0 = *reinterpret_cast<const double2 *>(A + pv), p1 = *reinterpret_cast<const double2 *>(A + pv + 2);
+        double c, sn;
+        jacobi_rotation(p0.x, p0.y, p1.y, tol2, c, sn);
+        rot[tid] = double2{c, sn};
+      }
       __syncthreads();
-      if (tid < half) {  // round-robin pairing (same schedule as k_jacobi)
-        int a, b;
-        if (tid == 0) { a = np - 1; b = step; }
-        else { a = (step + tid) % (np - 1); b = (step - tid + np - 1) % (np - 1); }
-        const int p = min(a, b), q = max(a, b);
-        if (q < n) {
-          const double apq = A[p * JWS + q], app = A[p * JWS + p], aqq = A[q * JWS + q];
-          if (apq * apq > tol2 * fabs(app * aqq) && apq != 0.0) {
-            const double tau = (aqq - app) * rcp_nr(2.0 * apq);
-            const double w = 1.0 + tau * tau;
-            const double t = copysign(1.0, tau) * rcp_nr(fabs(tau) + w * rsqrt_nr(w));
-            const double c = rsqrt_nr(1.0 + t * t), sn = t * c;
-            cc[p] = c; tt[p] = -sn; pn[p] = q;
-            cc[q] = c; tt[q] = sn; pn[q] = p;
-            s_rot = 1;  // benign race: every writer stores 1
-          }
+      if (active) {
+        const double2 rj = rot[J];
+        if (a_role) {  // A' = J^T A J on the block (rows of pair I) x (columns of pair J)
+          const double2 ri = rot[I];
+          const double2 b0 = *reinterpret_cast<const double2 *>(A + in0), b1 = *reinterpret_cast<const double2 *>(A + in0 + 2);
+          // rows first: row p <- c p - s q, row q <- s p + c q; then the same on the columns
+          const double rpp = ri.x * b0.x - ri.y * b1.x, rpq = ri.x * b0.y - ri.y * b1.y, rqp = ri.y * b0.x + ri.x * b1.x, rqq = ri.y * b0.y + ri.x * b1.y;
+          const double n1 = rj.y * rpp + rj.x * rpq;
+          An[o0] = rj.x * rpp - rj.y * rpq;
+          An[o1] = n1;
+          An[o2] = diag ? n1 : rj.x * rqp - rj.y * rqq;  // (a diagonal block's lower element is the upper one's copy)
+          An[o3] = rj.y * rqp + rj.x * rqq;
+        } else {  // V' = V J on (row i) x (columns of pair J)
+          const double vp = V[in0], vq = V[in0 + 1];
+          Vn[o0] = rj.x * vp - rj.y * vq;
+          Vn[o1] = rj.y * vp + rj.x * vq;
         }
       }
       __syncthreads();
-      const int pj = pn[j];
-      const double cj = cc[j], tj = tt[j];
-      double an[4], vn[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + 8 * u;  // rows >= n hold zeros / identity and are left alone
-        const int pi = pn[i];
-        const double ci = cc[i], ti = tt[i];
-        an[u] = ci * (cj * A[i * JWS + j] + tj * A[i * JWS + pj]) + ti * (cj * A[pi * JWS + j] + tj * A[pi * JWS + pj]);
-        vn[u] = cj * V[i * JWS + j] + tj * V[i * JWS + pj];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + 8 * u;
-        if (i < n) { A[i * JWS + j] = an[u]; V[i * JWS + j] = vn[u]; }
-      }
-      __syncthreads();
     }
-    const int any = s_rot;
+    // converged?  (what an empty sweep would find out in np - 1 steps: no pair left that the threshold would rotate;
+    // after a sweep every index is back in its seat, so block (I, J) holds a[2I..2I+1][2J..2J+1])
+    if (a_role && active && !lower) {
+      const double *A = Ab[cur];
+      const double2 b0 = *reinterpret_cast<const double2 *>(A + in0), b1 = *reinterpret_cast<const double2 *>(A + in0 + 2);
+      const double dI0 = A[(I * JHB + I) << 2], dI1 = A[((I * JHB + I) << 2) + 3], dJ0 = A[(J * JHB + J) << 2], dJ1 = A[((J * JHB + J) << 2) + 3];
+      auto big = [&](double apq, double app, double aqq) { return jacobi_needs(app, apq, aqq, tol2); };
+      const bool any = I == J ? big(b0.y, dI0, dI1) : (big(b0.x, dI0, dJ0) || big(b0.y, dI0, dJ1) || big(b1.x, dI1, dJ0) || big(b1.y, dI1, dJ1));
+      if (any) s_rot[sweep & 1] = 1;  // benign race: every writer stores 1
+    }
     __syncthreads();
-    if (tid == 0) s_rot = 0;
-    if (any == 0) { ++sweep; break; }  // a whole sweep without a rotation (uniform)
+    const int more = s_rot[sweep & 1];
+    if (tid == 0) s_rot[(sweep + 1) & 1] = 0;  // (the other flag: read last a sweep ago, written next a sweep from now, barriers between)
+    if (more == 0) { ++sweep; break; }  // (uniform)
   }
   if (tid == 0) *sweeps_done = sweep;
-  for (int e = tid; e < n * n; e += 256) {
+  for (int e = tid; e < n * n; e += (int)blockDim.x) {  // (a whole number of sweeps: every index is back in its seat)
     const int i = e / n, jj = e % n;
-    Ag[e] = A[i * JWS + jj];
-    Vg[e] = V[i * JWS + jj];
+    Ag[e] = Ab[cur][jblk(i, jj)];
+    Vg[e] = Vb[cur][i * JWS + jj];
   }
 }
 
@@ -642,7 +707,7 @@ void launch_jacobi(mvsvd_handle *h, double *dVout, double tol) {
   const int n = h->n, np = (n + 1) & ~1;
   const size_t nn = (size_t)n * n, jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
   if (n <= JW)
-    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, h->st, h->dG, dVout, n, 60, tol, h->dsw);
+    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(JHB * JHB + JW * (np / 2)), 0, h->st, h->dG, dVout, n, 60, tol, h->dsw);  // (A blocks + V pieces)
   else if (n <= 64)
     hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, h->dG, dVout, n, 60, tol, h->dsw);
   else
