@@ -49,18 +49,19 @@ typedef double svd_d4 __attribute__((ext_vector_type(4)));
 // value per lane per tile, converted to fp64 on load.  C/D: col = l & 15, row = (l >> 4) + 4 reg.
 // Partial tiles go to partial[chunk][pair][256] (no atomics: millions of f64 adds onto a
 // 24 x 24 matrix serialise at the memory side); k_gram_reduce sums the chunks in fixed order.
+// `red`: npairs x 8 KiB of LDS the caller no longer needs (24 KiB of STATIC shared memory here once held a block of the
+// fused kernel to 36 KiB: four blocks per CU instead of eight, one wave per SIMD too few to keep the matrix core fed)
 __device__ __forceinline__ void gram_store_partial(const svd_d4 *acc, int npairs, int pair0, int pairs_total,
-                                                   double *__restrict__ partial) {
-  __shared__ double red[4][3][4][64];
+                                                   double *__restrict__ partial, double *red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int q = 0; q < npairs; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][q][r][lane] = acc[q][r];
+    for (int r = 0; r < 4; ++r) red[((wave * npairs + q) * 4 + r) * 64 + lane] = acc[q][r];
   __syncthreads();
   double *out = partial + ((size_t)blockIdx.y * pairs_total + pair0) * 256;
   for (int e = threadIdx.x; e < npairs * 256; e += 256) {
-    const int q = e >> 8, r = (e >> 6) & 3, l = e & 63;
-    out[e] = red[0][q][r][l] + red[1][q][r][l] + red[2][q][r][l] + red[3][q][r][l];
+    const int q = e >> 8, rl = e & 255;  // rl = r * 64 + lane
+    out[e] = (red[((0 * npairs + q) << 8) + rl] + red[((1 * npairs + q) << 8) + rl]) + (red[((2 * npairs + q) << 8) + rl] + red[((3 * npairs + q) << 8) + rl]);
   }
 }
 
@@ -95,14 +96,17 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
     const int c = MODE == 2 ? (t == 0 ? li : (t == 1 ? 8 + li : (li < 8 ? 16 + li : li - 8))) : GT * t + li;
     cok[t] = c < n; col[t] = min(c, n - 1); muc[t] = mu ? mu[col[t]] : 0.0;
   }
+  // (PMC: the general operand path -- subtract the mean, mask absent columns and rows past the end -- was 12 vector
+  // instructions per MFMA, 122 M issue cycles next to 160 M of matrix-core time, and the two did not overlap)
+  const bool lean = mu == nullptr && n == (MODE == 1 ? 16 : (MODE == 2 ? 24 : 32));
   const long long total = n_rows * n;
   const int nvec = GRAM_ROWS * n / VEC;  // GRAM_ROWS * n is a multiple of 4
-  for (long long r0 = (long long)blockIdx.y * GRAM_ROWS; r0 < n_rows; r0 += (long long)gridDim.y * GRAM_ROWS) {
-    const long long e0 = r0 * n;  // first element of the step: 16-byte aligned (r0 is a multiple of 128)
-    constexpr int MAXV = GRAM_ROWS * 32 / VEC / 256;  // n <= 32: at most this many vectors per thread
-    vec_t xs[MAXV];
+  constexpr int MAXV = GRAM_ROWS * 32 / VEC / 256;  // n <= 32: at most this many vectors per thread
+  vec_t xs[MAXV];
+  auto load_step = [&](long long r0) {  // every load of a step is issued before anything waits for one
+    const long long e0 = r0 * n;        // first element of the step: 16-byte aligned (r0 is a multiple of 128)
 #pragma unroll
-    for (int u = 0; u < MAXV; ++u) {  // every load of the step is issued before the first LDS store
+    for (int u = 0; u < MAXV; ++u) {
       const int v = threadIdx.x + 256 * u;
       const long long idx = e0 + (long long)v * VEC;
       if (v < nvec && idx + VEC <= total) {
@@ -112,22 +116,32 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
         for (int w = 0; w < VEC; ++w) xs[u][w] = (v < nvec && idx + w < total) ? Wt[idx + w] : (T)0;
       }
     }
+  };
+  const long long r_first = (long long)blockIdx.y * GRAM_ROWS, r_stride = (long long)gridDim.y * GRAM_ROWS;
+  if (r_first < n_rows) load_step(r_first);
+  for (long long r0 = r_first; r0 < n_rows; r0 += r_stride) {
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) {
       const int v = threadIdx.x + 256 * u;
       if (v < nvec) *reinterpret_cast<vec_t *>(stage + (size_t)v * VEC) = xs[u];
     }
     __syncthreads();
+    if (r0 + r_stride < n_rows) load_step(r0 + r_stride);  // the next step's rows travel while this step's are multiplied
     const T *rows = stage + (size_t)(wave * ROWS_PER_STEP + lk) * n;
     const long long row0 = r0 + wave * ROWS_PER_STEP + lk;
 #pragma unroll
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
       double v[NC];
-      const bool rok = row0 + 4 * g < n_rows;  // rows past the end are zeros in LDS: keep them zero when centring
+      if (lean) {  // (uniform) no centring, every operand column exists: a row past the end is zeros in LDS and stays zero
 #pragma unroll
-      for (int t = 0; t < NC; ++t) {
-        const double x = (double)rows[(size_t)(4 * g) * n + col[t]] - muc[t];
-        v[t] = (cok[t] && rok) ? x : 0.0;
+        for (int t = 0; t < NC; ++t) v[t] = (double)rows[(4 * g) * n + col[t]];
+      } else {
+        const bool rok = row0 + 4 * g < n_rows;  // rows past the end are zeros in LDS: keep them zero when centring
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+          const double x = (double)rows[(size_t)(4 * g) * n + col[t]] - muc[t];
+          v[t] = (cok[t] && rok) ? x : 0.0;
+        }
       }
       if (MODE == 2) {
         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0], v[0], acc[0], 0, 0, 0);
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gram_fused(const T *__restrict__ Wt, lo
     }
     __syncthreads();
   }
-  gram_store_partial(acc, NP, 0, NP, partial);
+  gram_store_partial(acc, NP, 0, NP, partial, gram_lds_raw);  // (the staging buffer: the last step ended with a barrier)
 }
 
 // larger n: blockIdx.x = one upper tile pair (the rows are re-read once per pair, from L2 / MALL)
@@ -172,7 +186,8 @@ __global__ __launch_bounds__(256) void k_gram_pair(const T *__restrict__ Wt, lon
 #pragma unroll
     for (int g = 0; g < ROWS_PER_STEP / 4; ++g) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[g], vb[g], acc[0], 0, 0, 0);
   }
-  gram_store_partial(acc, 1, blockIdx.x, n_pairs, partial);
+  __shared__ double red1[4 * 4 * 64];
+  gram_store_partial(acc, 1, blockIdx.x, n_pairs, partial, red1);
 }
 
 // Two fixed-order levels instead of atomics: k_gram_reduce sums a slice of the row chunks per block
@@ -689,11 +704,11 @@ void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) {
   const bool packed = n > 16 && n <= 24;
   const int n_pairs = packed ? 2 : n_tiles * (n_tiles + 1) / 2;
   if (n <= 16)
-    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 1 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
   else if (packed)
-    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 2 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
   else if (n <= 32)
-    hipLaunchKernelGGL((k_gram_fused<T, 3>), dim3(1, chunks), dim3(256), sizeof(T) * GRAM_ROWS * n, h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 3>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 3 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
   else
     hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, h->st, W, h->n_rows, n, n_tiles, n_pairs, mu, h->dpart);
   const int slices = std::min(chunks, GRAM_SLICES);
