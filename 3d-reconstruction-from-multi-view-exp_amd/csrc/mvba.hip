@@ -2501,7 +2501,7 @@ struct mvba_handle {
   std::vector<double *> snap_slabs;
   long long n_snap = 0;
   // profiling
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every phase, 2 the Schur and residual-Jacobian kernels only (mvba_set_profiling)
   mvba_stats stats{};
   struct Ev { int kid; hipEvent_t a, b; };
   std::vector<Ev> pending;
@@ -2517,8 +2517,12 @@ struct Timed {
   mvba_handle *h;
   int kid;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
   Timed(mvba_handle *h_, int kid_) : h(h_), kid(kid_) {
-    if (!h->profiling) return;
+    // level 2: the two kernels a roofline is quoted for, nothing else (every timed phase is two marker packets on the
+    // stream and ~10 us of a 2.5 ms step)
+    on = h->profiling == 1 || (h->profiling == 2 && (kid == MVBA_K_SCHUR || kid == MVBA_K_RESID_JAC));
+    if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
@@ -2529,7 +2533,7 @@ struct Timed {
     hipEventRecord(a, h->stream);
   }
   ~Timed() {
-    if (!h->profiling) return;
+    if (!on) return;
     hipEventRecord(b, h->stream);
     h->pending.push_back({kid, a, b});
   }
@@ -3672,7 +3676,7 @@ int mvba_snapshot_clear(mvba_handle *h) {
 
 int mvba_set_profiling(mvba_handle *h, int32_t enabled) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
-  h->profiling = enabled != 0;
+  h->profiling = enabled == 2 ? 2 : (enabled != 0);
   return MVBA_OK;
 }
 

@@ -213,7 +213,8 @@ class HipEngine:
 
     # -- measurement / multi-GPU / test hooks
     def set_profiling(self, on):
-        raise_for(self.lib.mvba_set_profiling(self._h, int(bool(on))), self.lib)
+        """False / True, or 2: time the Schur and residual-Jacobian kernels only."""
+        raise_for(self.lib.mvba_set_profiling(self._h, 2 if on == 2 and on is not True else int(bool(on))), self.lib)
 
     def reset_stats(self):
         raise_for(self.lib.mvba_reset_stats(self._h), self.lib)

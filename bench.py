@@ -360,15 +360,20 @@ def main():
         lm.carry_on(E_)
         return E_
 
-    for _ in range(args.warmup):
-        one_step()
-    eng.set_profiling(True)
-    eng.reset_stats()
-    solves0 = eng.n_solves
     # (as `timeit` does: no cyclic-GC pass inside the timed region -- with torch imported a full collection walks
-    # ~10^6 objects and shows up as one 50-60 ms step in a run of 2.5 ms steps, about once in a hundred steps)
+    # ~10^6 objects and shows up as one 50-60 ms step in a run of 2.5 ms steps, about once in a hundred steps.  The
+    # explicit collection comes BEFORE the warm-up: it leaves the CPU's caches full of everything but the launch path,
+    # and the steps right after it were 0.1-0.3 ms slower on the host side)
     gc.collect()
     gc.disable()
+    # Device timers (hipEvents on the engine's stream) in the timed region: the two kernels a roofline is quoted for
+    # (K3, K1) only -- every timed phase is two marker packets on the stream, and with all eight phases timed a step
+    # was ~0.07 ms (3 %) longer.  The full per-kernel table comes from a separate, untimed pass right after.
+    eng.set_profiling(2)  # (before the warm-up: its steps also create the hipEvents the timers recycle)
+    for _ in range(args.warmup):
+        one_step()
+    eng.reset_stats()
+    solves0 = eng.n_solves
     fence()
     t0 = time.perf_counter()
     restarts0 = n_restarts
@@ -380,8 +385,20 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host clock per step: shows a stalled step next to the mean
+    if os.environ.get("MVBA_BENCH_STEP_DUMP") and rank == 0:
+        print("step_ms:", " ".join(f"{v:.3f}" for v in step_ms), file=sys.stderr)
     st = eng.stats()
     n_solves = eng.n_solves - solves0
+    # every phase timed, outside the timed region: TABLE_STEPS more steps of the same loop
+    TABLE_STEPS = 6
+    eng.set_profiling(True)
+    one_step()  # (creates the additional events)
+    eng.reset_stats()
+    solves_t0 = eng.n_solves
+    for _ in range(TABLE_STEPS):
+        one_step()
+    st_table = eng.stats()
+    table_solves = eng.n_solves - solves_t0
     eng.set_profiling(False)
 
     # The same schedule through the PUBLIC surface: BundleAdjuster.optimize(2.0, -1.0, 10)
@@ -469,7 +486,7 @@ def main():
                 "ranks_per_device": (world / max(torch.cuda.device_count(), 1) if host_transport and multi else 1),
             },
             # C1: one all-reduce of the packed [A|b] per inner solve (+ the 16-byte cost/status all-gather)
-            "allreduce": ({"ms_per_solve": st["allreduce"]["ms"] / max(n_solves, 1),
+            "allreduce": ({"ms_per_solve": st_table["allreduce"]["ms"] / max(table_solves, 1),
                            "bytes_per_solve": 8 * (81 * n_cams * (n_cams + 1) // 2 + 9 * n_cams), "ranks": world,
                            "transport": args.transport} if multi else None),
             "resid_jac_gobs_per_s": n_obs_total / (k1_ms * 1e-3) / 1e9,
@@ -486,7 +503,10 @@ def main():
                               "frac": step_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                         "argmax": int(step_ms.argmax())},
-            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in st.items() if k != "counts"},
+            "kernel_ms_per_step": {k: (st[k]["ms"] / args.steps if k in ("resid_jac", "schur") else v["ms"] / TABLE_STEPS)
+                                   for k, v in st_table.items() if k != "counts"},
+            "kernel_ms_per_step_source": f"resid_jac and schur: hipEvents inside the timed region; the other phases: a separate pass of "
+                                         f"{TABLE_STEPS} steps right after it with every phase timed (timing all of them costs ~3 % of a step)",
         }
         if not args.no_cpu_baseline and world == 1:  # CPU baseline and SVD leg: rank 0 at N = 1 only
             eng.close()

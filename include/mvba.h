@@ -114,7 +114,8 @@ int mvba_snapshot_read(mvba_handle *h, int64_t i, double *X, double *f, double *
 int mvba_snapshot_clear(mvba_handle *h);
 int mvba_snapshot_restore(mvba_handle *h, int64_t i);
 
-/* Per-kernel device timing; off by default. */
+/* Per-kernel device timing (hipEvents on the engine's stream); off by default.  enabled = 1: every phase;
+ * 2: the Schur (K3) and residual-Jacobian (K1) kernels only -- each timed phase is two marker packets on the stream. */
 int mvba_set_profiling(mvba_handle *h, int32_t enabled);
 int mvba_get_stats(mvba_handle *h, mvba_stats *out);
 int mvba_reset_stats(mvba_handle *h);
