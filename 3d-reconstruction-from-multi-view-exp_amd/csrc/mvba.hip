@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -2180,15 +2181,26 @@ __global__ __launch_bounds__(256) void k_cost(long long nobs, int m, const doubl
 
 // out[0] = cost; the status flags ride along in the next 8 bytes so that the host needs ONE
 // 16-byte device-to-host copy per trial step.
+// `mail` (may be null): the same two words once more in pinned HOST memory, then -- behind a system-scope fence -- the
+// sequence number the host is spinning on: the cost reaches the LM loop without a copy kernel and without waking a
+// thread that sleeps in hipStreamSynchronize (~35 us between the last kernel of a step and the first of the next).
 __global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partials, int n,
-                                                       double *__restrict__ out, const int *__restrict__ flag) {
+                                                       double *__restrict__ out, const int *__restrict__ flag,
+                                                       double *mail, unsigned long long seq) {
   __shared__ double s_red[16];
   double v = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
   const double t = block_sum(v, s_red);
   if (threadIdx.x == 0) {
+    const int fl = *flag;
     out[0] = t;
-    reinterpret_cast<int *>(out + 1)[0] = *flag;
+    reinterpret_cast<int *>(out + 1)[0] = fl;
+    if (mail) {
+      mail[0] = t;
+      reinterpret_cast<int *>(mail + 1)[0] = fl;
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -2485,6 +2497,9 @@ struct mvba_handle {
   int *d_ipiv = nullptr;
   // cost
   double *d_partials = nullptr, *d_cost = nullptr, *h_cost = nullptr;
+  double *d_mail = nullptr;               // device address of h_cost (pinned, mapped): the cost kernel's mailbox
+  unsigned long long cost_seq = 0;
+  bool mail_pending = false;
   int n_partials = 0, cost_grid = 0;
   int *d_flag = nullptr, *h_flag = nullptr;
   unsigned *d_bar = nullptr;
@@ -2568,7 +2583,45 @@ int sync_and_drain(mvba_handle *h) {
 // every rank, so that all ranks take the same accept/reject, LU-rescue and error decisions (a
 // rank that branched alone would leave the others waiting in the next collective).  (C1b: one
 // all-gather of 16 bytes per rank per trial, on top of C1.)
+inline void cpu_relax() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  __builtin_ia32_pause();
+#endif
+}
+
+// Single rank, not every phase timed: the cost kernel mails its result to pinned host memory (see k_sum_partials).
+// Returns the device address of the mailbox and advances the sequence number, or null for the copy + sync path.
+double *cost_mail(mvba_handle *h) {
+  if (h->comm || h->host_ar || h->profiling == 1 || !h->d_mail) return nullptr;
+  ++h->cost_seq;
+  h->mail_pending = true;
+  return h->d_mail;
+}
+
 int global_cost(mvba_handle *h, double *E) {
+  if (h->mail_pending) {
+    h->mail_pending = false;
+    volatile unsigned long long *seq = reinterpret_cast<volatile unsigned long long *>(h->h_cost + 2);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned spins = 0;; ++spins) {
+      if (*seq == h->cost_seq) { seen = true; break; }
+      // (everything earlier on the stream is complete once the number has arrived; if it does not arrive -- a fault, a
+      // hung kernel -- the ordinary synchronisation below reports what happened)
+      if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+      cpu_relax();
+    }
+    if (seen) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      drain_events(h);  // (level 2: the timers of K1 and K3 ended before the cost kernel started)
+      *E = h->h_cost[0];
+      return MVBA_OK;
+    }
+    int rc = sync_and_drain(h);
+    if (rc) return rc;
+    *E = h->h_cost[0];
+    return MVBA_OK;
+  }
   if (h->comm) {
     Timed t(h, MVBA_K_ALLREDUCE);
     ncclResult_t r = g_rccl.AllGather(h->d_cost, h->d_allcost, 2, ncclDouble, h->comm, h->stream);
@@ -2611,7 +2664,8 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
   hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
                      h->d_cam, h->d_xy, h->f0, h->d_partials);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, cost_mail(h),
+                     h->cost_seq);
   MVBA_HIP(hipGetLastError());
   return MVBA_OK;
 }
@@ -3237,7 +3291,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_cost, 2));
   TRY(dmalloc(&h->d_flag, 1));
   TRY(dmalloc(&h->d_bar, 1));
-  TRYH(hipHostMalloc((void **)&h->h_cost, 2 * sizeof(double)));
+  TRYH(hipHostMalloc((void **)&h->h_cost, 4 * sizeof(double), hipHostMallocMapped));
+  memset(h->h_cost, 0, 4 * sizeof(double));
+  if (hipHostGetDevicePointer((void **)&h->d_mail, h->h_cost, 0) != hipSuccess) h->d_mail = nullptr;  // (no mapping: copy + sync as before)
   h->h_flag = reinterpret_cast<int *>(h->h_cost + 1);  // cost and flags come back in one copy
   if (nobs) {
     TRYH(hipMemcpy(h->d_obs_pt, obs_pt.data(), sizeof(int) * nobs, hipMemcpyHostToDevice));
@@ -3548,7 +3604,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const size_t clds = (size_t)h->m * CAM_LDS * sizeof(double);
     hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial], h->d_X[trial],
                        h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, cost_mail(h),
+                       h->cost_seq);
   };
   launch_tail();
   MVBA_HIP(hipGetLastError());
