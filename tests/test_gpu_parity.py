@@ -746,6 +746,37 @@ def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypa
         np.testing.assert_array_equal(dev[k], host[k], err_msg=k)
 
 
+def test_cost_mailbox_and_timer_levels_agree_with_the_synchronous_path():
+    """The trial cost reaches the host either through the cost kernel's mailbox in pinned memory (no timers, or
+    mvba_set_profiling level 2) or through a copy + stream synchronisation (every phase timed): the same numbers, bit
+    for bit, over a few LM steps -- and level 2 times the Schur and residual-Jacobian kernels only."""
+    sc = make_scene(4000, 10, vis_p=0.6)
+
+    def run(level):
+        ba = BundleAdjuster.from_observations(sc.n_points, 10, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
+                                              sc.init_R, sc.init_t, axis=sc.axis)
+        eng = ba._engine
+        eng.set_profiling(level)
+        out = [eng.cost()]
+        c = 1e-3
+        for _ in range(4):
+            eng.linearize()
+            E1 = eng.try_step(c)
+            out.append(E1)
+            if E1 <= out[0]:
+                eng.commit()
+            c *= 0.5
+        return out, eng.stats()
+
+    e0, _ = run(False)
+    e1, st1 = run(True)
+    e2, st2 = run(2)
+    assert e0 == e1 == e2
+    assert st1["solve"]["launches"] > 0 and st1["backsub_cost"]["launches"] > 0
+    assert st2["schur"]["launches"] == 4 and st2["resid_jac"]["launches"] == 4
+    assert st2["solve"]["launches"] == 0 and st2["backsub_cost"]["launches"] == 0 and st2["point_inv"]["launches"] == 0
+
+
 def test_snapshot_restore_brings_back_a_logged_state():
     """mvba_snapshot_restore = set_params from the device-resident log: after some LM steps, restoring entry 0
     gives the initial cost and the initial parameters again, bit for bit, and the next trial is the first one's."""
