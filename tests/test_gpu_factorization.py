@@ -175,6 +175,23 @@ def test_fp64_centring_with_a_large_mean():
     np.testing.assert_allclose(S, M.T @ (Wt - mu).T, rtol=0, atol=1e-9 * np.abs(S).max())
 
 
+@pytest.mark.parametrize("n_cols", [1, 2, 3, 4, 5, 7, 16, 17, 23, 31, 32, 33, 48])
+def test_every_order_of_the_small_eigen_solver(n_cols):
+    """k_jacobi_small (up to 32 columns: fixed pairs with the data moving between two buffers, an odd order padded by a
+    phantom index that is never rotated, one pair only at 2 columns) and the first orders past it: every singular
+    value, the left basis orthonormal and M S = the rank-r truncation, against LAPACK in float64."""
+    rng = np.random.default_rng(100 + n_cols)
+    rows = 3000
+    r = min(3, n_cols)
+    Wt = rng.standard_normal((rows, n_cols)) * np.logspace(0, -3, n_cols)[None, :] + rng.standard_normal((rows, 1)) @ rng.standard_normal((1, n_cols))
+    M, sig, S, _mu, tm = _mvba.svd_factorize(np.ascontiguousarray(Wt), r)
+    U, s_ref, Vt = np.linalg.svd(Wt.T, full_matrices=False)  # W = Wt^T is (n_cols, rows)
+    np.testing.assert_allclose(sig, s_ref, rtol=1e-9, atol=1e-12 * s_ref[0])
+    np.testing.assert_allclose(M.T @ M, np.eye(r), atol=1e-12)
+    np.testing.assert_allclose(M @ S, (U[:, :r] * s_ref[:r]) @ Vt[:r], atol=1e-8 * s_ref[0])
+    assert tm["sweeps"] < 30
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_any_rank_and_workspace_reuse(dtype):
     """n_rank beyond 4 (the reference takes any rank, ref factorization.py:6,12-13) and the resident
