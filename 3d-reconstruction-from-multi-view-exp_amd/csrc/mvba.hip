@@ -1722,9 +1722,10 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double *M, int ld, int D
 }
 
 // Device-wide barrier of a persistent grid (every workgroup co-resident: at most one per CU).  Every
-// workgroup reaches every barrier (the counts depend on D only), and a barrier gives up after ~2^22
-// polls (flag bit 8 -> MVBA_ERR_HIP on the host) instead of spinning for ever, so the grid always drains.
-__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int *flag) {
+// workgroup reaches every barrier (the counts depend on D only), and a barrier gives up after `max_polls`
+// polls (2^22 by default; flag bit 8 -> the host redoes the solve with one launch per super-block) instead of
+// spinning for ever, so the grid always drains.
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int *flag, unsigned max_polls) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's global writes are visible device-wide
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1732,7 +1733,7 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int
     unsigned spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) {
+      if (++spins > max_polls) {
         atomicOr(flag, 8);
         break;
       }
@@ -1756,7 +1757,7 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int
 // One barrier per step: x_s must reach the next chain and the bulk workgroups, their updates the chain.
 __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M, int ld, int D, int m, int gauge_axis,
                                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full,
-                                                                      int *flag, unsigned *bar) {
+                                                                      int *flag, unsigned *bar, unsigned max_polls) {
   extern __shared__ double lds[];
   const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *y = M + (size_t)D * ld;
@@ -1801,7 +1802,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
         if (w < NB * NB) Zs[tile][w >> 5][w & 31] = zl[tile][ps];  // Ls follows Zs: tile 4 + e lands in Ls[e]
       }
     // ---- wait for the step
-    for (int t = S - 1; t > s; --t) grid_barrier(bar, ++epoch * G, flag);
+    for (int t = S - 1; t > s; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
     // x_{s+1} (published by chain s+1 before the barrier) and y_s (complete but for the panel's share)
     const double yv = (tid < ns) ? y[jS + tid] : 0.0;
     double sa = 0.0, sb = 0.0;
@@ -1849,7 +1850,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
       dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
     }
     if (s == 0 && tid < 7) dxi_full[tid < 6 ? 3 + tid : 12 + gauge_axis] = 0.0;  // the removed (gauge) parameters
-    for (int t = s; t > 0; --t) grid_barrier(bar, ++epoch * G, flag);
+    for (int t = s; t > 0; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
     return;
   }
   // ================= bulk: at step s, columns left of block s, rows of block s+1
@@ -1886,7 +1887,7 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
         }
         __syncthreads();
       }
-    if (s > 0) grid_barrier(bar, ++epoch * G, flag);
+    if (s > 0) grid_barrier(bar, ++epoch * G, flag, max_polls);
   }
 }
 
@@ -2505,6 +2506,7 @@ struct mvba_handle {
   unsigned *d_bar = nullptr;
   int n_cu = 1;
   bool chol_onepass = true;  // L^T x = y as one persistent launch (MVBA_CHOL=launches: one launch per super-block)
+  unsigned barrier_polls = 1u << 22;  // what a device-wide barrier of that launch polls before it gives up (MVBA_CHOL_BARRIER_POLLS)
   // comm
   ncclComm_t comm = nullptr;
   mvba_host_allreduce_fn host_ar = nullptr;  // host-staged transport (mvba_comm_init_host) instead of RCCL
@@ -2664,8 +2666,9 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
   hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
                      h->d_cam, h->d_xy, h->f0, h->d_partials);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, cost_mail(h),
-                     h->cost_seq);
+  double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
+  const unsigned long long seq = h->cost_seq;
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, mail, seq);
   MVBA_HIP(hipGetLastError());
   return MVBA_OK;
 }
@@ -3361,6 +3364,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRYH(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_backsolve_all, SUPER_THREADS, BACKSOLVE_LDS));
     h->chol_onepass = per_cu >= 1 && !(getenv("MVBA_CHOL") && !strcmp(getenv("MVBA_CHOL"), "launches"));
+    if (const char *ev = getenv("MVBA_CHOL_BARRIER_POLLS")) h->barrier_polls = (unsigned)std::max(0LL, atoll(ev));
   }
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
@@ -3554,7 +3558,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       h->stats.launches[MVBA_K_ALLREDUCE] += 1;
     }
   }
-  {
+  auto launch_solve = [&](bool onepass) {  // K4: gauge strip, blocked Cholesky, back-substitution
     Timed t(h, MVBA_K_SOLVE);
     const int ld = h->ld;
     hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
@@ -3569,13 +3573,13 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       }
     }
     const int S = (D + SBW - 1) / SBW;
-    if (h->chol_onepass && (S == 1 || S < h->n_cu)) {  // one persistent pass for L^T x = y (see k_chol_backsolve_all)
+    if (onepass && (S == 1 || S < h->n_cu)) {  // one persistent pass for L^T x = y (see k_chol_backsolve_all)
       // few bulk workgroups (each then takes several column groups per step): a barrier gets dearer with
       // every workgroup -- its release/acquire writes back and invalidates that XCD's L2 for everybody on
       // it.  D = 4493: 16 bulk workgroups 2.75 ms per solve, 64: 2.93, 220: 3.24 (tools/ab_solve.py).
       const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(std::min(h->n_cu - S, 16), ngrp)) : 0;
       hipLaunchKernelGGL(k_chol_backsolve_all, dim3(S + nbulk), dim3(SUPER_THREADS), BACKSOLVE_LDS, h->stream, h->d_Ared, ld, D, m,
-                         h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar);
+                         h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->barrier_polls);
     } else
     for (int jS = ((D - 1) / SBW) * SBW; jS >= 0; jS -= SBW) {
       const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
@@ -3583,7 +3587,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       hipLaunchKernelGGL(k_chol_backsolve, dim3(nwg), dim3(256), 0, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles,
                          h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_dxi, jS, jE, jE2);
     }
-  }
+  };
+  launch_solve(h->chol_onepass);
   MVBA_HIP(hipGetLastError());
   const int trial = 1 - h->cur;
   auto launch_tail = [&]() {  // K6a + K5/K6: trial cameras, back-substitution, trial cost
@@ -3604,14 +3609,28 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const size_t clds = (size_t)h->m * CAM_LDS * sizeof(double);
     hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial], h->d_X[trial],
                        h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, cost_mail(h),
-                       h->cost_seq);
+    double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
+    const unsigned long long seq = h->cost_seq;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, mail, seq);
   };
   launch_tail();
   MVBA_HIP(hipGetLastError());
   h->stats.n_try_step++;
   int rc = global_cost(h, E_trial);
   if (rc) return rc;
+  if ((*h->h_flag & 8) && !(*h->h_flag & 1)) {
+    // A device-wide barrier of the persistent back-substitution gave up: its grid was not co-resident (another
+    // process holds CUs -- e.g. ranks sharing a GPU).  Nothing is lost but time: the packed [A|b] is intact, so the
+    // solve is redone with one launch per super-block (no barrier), and this handle stays on that path.
+    MVBA_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+    h->chol_onepass = false;
+    h->stats.n_barrier_fallback++;
+    launch_solve(false);
+    launch_tail();
+    MVBA_HIP(hipGetLastError());
+    rc = global_cost(h, E_trial);
+    if (rc) return rc;
+  }
   if ((*h->h_flag & 2) && !(*h->h_flag & (1 | 8))) {
     // The Cholesky met a non-positive pivot: the reduced system is not positive definite (e.g. a
     // negative damping factor).  The reference's np.linalg.solve is LU with partial pivoting and
@@ -3646,7 +3665,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   if (*h->h_flag) {
     const int fl = *h->h_flag;
     hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
-    if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_backsolve_all: a device-wide barrier timed out (is another process holding the CUs?)");
+    if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_backsolve_all: a device-wide barrier timed out twice (is another process holding the CUs?)");
     return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system)");
   }
   h->have_trial = true;

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(const T *__restrict__ X, con
 // Workspace: the resident matrix and every buffer a factorisation needs, allocated once.
 struct mvsvd_handle {
   int device = 0, dtype = 0, n = 0;
-  long long max_rows = 0, n_rows = 0;
+  long long max_rows = 0, n_rows = 0, base_rows = 0;  // rows of the loaded matrix (dW) / of the resident base (dX)
   hipStream_t st = nullptr;
   hipEvent_t ev[6] = {};
   void *dW = nullptr, *dS = nullptr;
@@ -911,7 +911,7 @@ int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows) {
   if (!h->dX) MVBA_HIP(hipMalloc(&h->dX, el * (size_t)h->max_rows * h->n));
   MVBA_HIP(hipMemcpyAsync(h->dX, X, el * (size_t)n_rows * h->n, hipMemcpyHostToDevice, h->st));
   MVBA_HIP(hipStreamSynchronize(h->st));
-  h->n_rows = n_rows;
+  h->base_rows = n_rows;
   h->base_loaded = true;
   h->loaded = false;  // dW holds nothing derived from this base yet
   return MVBA_OK;
@@ -931,24 +931,25 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   constexpr int GS_BLOCKS = 512;
   if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
   if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
+  h->n_rows = h->base_rows;  // dW is about to hold the re-weighted base (a mvsvd_load in between may have changed it)
   hipEventRecord(h->ev[0], h->st);
-  MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->n_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
+  MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
   hipEventRecord(h->ev[1], h->st);
   double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
-  const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->n_rows + 255) / 256));
-  const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->n_rows / 64 + 1));
+  const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->base_rows + 255) / 256));
+  const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->base_rows / 64 + 1));
   if (h->dtype == 0) {
     if (norm == 2) {
-      hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->n_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, h->dgs);
       hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
     }
-    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->n_rows, h->n, group, norm, cs, (float *)h->dW);
+    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
   } else {
     if (norm == 2) {
-      hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->n_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, h->dgs);
       hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
     }
-    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->n_rows, h->n, group, norm, cs, (double *)h->dW);
+    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
   }
   MVBA_HIP(hipStreamSynchronize(h->st));
   float ms = 0.f;

@@ -33,7 +33,7 @@ class Problem(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ms", C.c_double * 16), ("launches", C.c_int64 * 16),
                 ("n_linearize", C.c_int64), ("n_try_step", C.c_int64), ("n_commit", C.c_int64),
-                ("n_lu_fallback", C.c_int64)]
+                ("n_lu_fallback", C.c_int64), ("n_barrier_fallback", C.c_int64)]
 
 
 # every symbol include/mvba.h declares: (restype, argtypes)
@@ -224,7 +224,7 @@ class HipEngine:
         raise_for(self.lib.mvba_get_stats(self._h, C.byref(s)), self.lib)
         out = {k: {"ms": s.ms[i], "launches": s.launches[i]} for i, k in enumerate(KERNEL_IDS)}
         out["counts"] = {"linearize": s.n_linearize, "try_step": s.n_try_step, "commit": s.n_commit,
-                         "lu_fallback": s.n_lu_fallback}
+                         "lu_fallback": s.n_lu_fallback, "barrier_fallback": s.n_barrier_fallback}
         return out
 
     def _info(self):
@@ -321,7 +321,7 @@ class SvdWorkspace:
         self.dtype = np.dtype(dtype)
         if self.dtype not in (np.float32, np.float64):
             raise ValueError("dtype must be float32 or float64")
-        self.max_rows, self.n_cols, self.n_rows = int(max_rows), int(n_cols), 0
+        self.max_rows, self.n_cols, self.n_rows, self.base_rows = int(max_rows), int(n_cols), 0, 0
         h = C.c_void_p()
         raise_for(self.lib.mvsvd_create(self.max_rows, self.n_cols, 0 if self.dtype == np.float32 else 1, int(device),
                                         C.byref(h)), self.lib)
@@ -341,7 +341,7 @@ class SvdWorkspace:
         if X.ndim != 2 or X.shape[1] != self.n_cols:
             raise ValueError("X must be (n_rows, n_cols) of the workspace")
         raise_for(self.lib.mvsvd_load_base(self._h, X.ctypes.data, X.shape[0]), self.lib)
-        self.n_rows = X.shape[0]
+        self.base_rows = X.shape[0]
         return self
 
     def run_scaled(self, z, group, norm, n_rank):
@@ -349,8 +349,9 @@ class SvdWorkspace:
         2 = column groups by their squared norm) from the resident base: only z is uploaded.
         M (n_cols, r), sigma (n_cols,), S (r, n_rows), timings."""
         z = np.ascontiguousarray(z, dtype=self.dtype)
-        if z.shape != (self.n_rows, self.n_cols // int(group)):
-            raise ValueError("z must be (n_rows, n_cols / group)")
+        if z.shape != (self.base_rows, self.n_cols // int(group)):
+            raise ValueError("z must be (rows of the base, n_cols / group)")
+        self.n_rows = self.base_rows  # the workspace matrix becomes the re-weighted base
         M = np.empty((self.n_cols, n_rank), self.dtype)
         sigma = np.empty(self.n_cols, self.dtype)
         S = np.empty((n_rank, self.n_rows), self.dtype)

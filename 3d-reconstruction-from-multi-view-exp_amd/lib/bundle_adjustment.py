@@ -14,6 +14,7 @@ There is no CPU fallback.
 """
 from __future__ import annotations
 
+import os
 from typing import Any
 
 import numpy as np
@@ -177,38 +178,47 @@ class BundleAdjuster:
         if is_debug:
             self._log.clear()  # ref :90
             self._log_errors = []
-            on_device = hasattr(self._engine, "snapshot")
-            if on_device:
-                self._engine.snapshot_clear()
+            self._engine.snapshot_clear()
+            # The log lives in device memory while optimize() runs: 24 N + 120 m bytes per outer iteration (24 MB at
+            # 1 M points, 240 MB at 10 M), one device-to-device copy on the engine's stream per entry.  Above
+            # MVBA_LOG_DEVICE_BYTES (default 16 GiB), or when the device cannot allocate the next slab, the entries
+            # gathered so far are fetched to the host (as get_log() would) and the device log starts over.
+            entry_bytes = 24 * self._n_points + 120 * self._n_images
+            budget = int(os.environ.get("MVBA_LOG_DEVICE_BYTES", str(16 << 30)))
 
             def on_state(err):  # log entries are copies, normalised frame (ref :91-97, :175-183)
-                if on_device:  # a device-to-device copy on the engine's stream; fetched by get_log()
+                if (len(self._log_errors) + 1) * entry_bytes > budget and self._log_errors:
+                    self._fetch_log()
+                try:
                     self._engine.snapshot()
-                    self._log_errors.append(err)
-                else:  # engines that keep their state on the host (the test oracle)
-                    X, _, _, t, R = self._engine.get_params()
-                    self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": err})
+                except RuntimeError:  # out of device memory for the next slab
+                    if not self._log_errors:
+                        raise
+                    self._fetch_log()
+                    self._engine.snapshot()
+                self._log_errors.append(err)
 
         lm_loop(self._engine, scale_factor, delta_tol, max_iter, on_state)
         # the reference rebinds its state to the de-normalised values (:198-200): the engine applies
         # the way back (:242-258) to its committed state on the device, then hands it over
         cam0 = self._init_camera0_params
-        if hasattr(self._engine, "apply_similarity"):
-            self._engine.apply_similarity(cam0["R"], cam0["t"], cam0["c0c1_len"])
-            X, f, u, t, R = self._engine.get_params()
-        else:  # engines that keep their state on the host (the test oracle)
-            X, f, u, t, R = self._engine.get_params()
-            X, R, t = from_gauge_frame(cam0, X, R, t)
-            self._engine.set_params(X, f, u, t, R)
+        self._engine.apply_similarity(cam0["R"], cam0["t"], cam0["c0c1_len"])
+        X, f, u, t, R = self._engine.get_params()
         return X, intrinsics_from(f, u, self._f0), R, t
 
+    def _fetch_log(self):
+        """Device-resident log entries -> host dicts (in order), device log emptied."""
+        for i, err in enumerate(self._log_errors):
+            X, _, _, t, R = self._engine.snapshot_read(i)
+            self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": err})
+        self._log_errors = []
+        self._engine.snapshot_clear()
+
     def get_log(self) -> list[dict[str, npt.NDArray | float]]:
-        """ref :204-206.  On the device path the per-iteration states were kept in device memory while
-        optimize() ran (`mvba_snapshot`); they cross PCIe here, once, the first time the log is asked for."""
-        pending = getattr(self, "_log_errors", None)
-        if pending:
-            for i in range(len(self._log), len(pending)):
-                X, _, _, t, R = self._engine.snapshot_read(i)
-                self._log.append({"points": X, "basis": R, "pos": t, "reprojection_error": pending[i]})
-            self._log_errors = []
+        """ref :204-206.  The per-iteration states were kept in device memory while optimize(is_debug=True) ran
+        (`mvba_snapshot`, 24 N + 120 m bytes each); they cross PCIe here, once, the first time the log is asked
+        for.  (The device log belongs to this adjuster's engine: code that drives `_engine.snapshot*` itself between
+        optimize() and get_log() -- bench.py's episode restarts do, without is_debug -- would replace its entries.)"""
+        if getattr(self, "_log_errors", None):
+            self._fetch_log()
         return self._log

@@ -42,6 +42,7 @@ class _GpuSvd4:
         if self._ws is None or self._ws.max_rows < Wt.shape[0] or self._ws.n_cols != Wt.shape[1] or self._ws.dtype != Wt.dtype:
             if self._ws is not None:
                 self._ws.close()
+            self._base = None  # (the new workspace holds no base)
             self._ws = SvdWorkspace(Wt.shape[0], Wt.shape[1], Wt.dtype if Wt.dtype in (np.float32, np.float64) else np.float64)
         M, sigma, S, _mu, _tm = self._ws.load(Wt).run(4)
         return M, sigma, S

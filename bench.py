@@ -236,9 +236,12 @@ def self_launch(argv, n_gpus):
     line = None
     for ln in proc.stdout.splitlines():
         try:
-            if "metric" in json.loads(ln):
-                line = ln
+            obj = json.loads(ln)
         except ValueError:
+            obj = None
+        if isinstance(obj, dict) and "metric" in obj:
+            line = ln
+        else:
             print(ln, file=sys.stderr)
     if line is not None:
         print(line, flush=True)

@@ -6,10 +6,12 @@ from lib.bundle_adjustment import BundleAdjuster, dense_to_observations
 from lib.synthetic import make_scene
 from oracle import ba_oracle as O
 
+from _engines import HostOracleEngine
+
 
 class _OracleBA(BundleAdjuster):
     def _make_engine(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, **kw):
-        return O.OracleEngine(n_points, n_images, pt_ptr, cam_idx, xy, f0, axis)
+        return HostOracleEngine(n_points, n_images, pt_ptr, cam_idx, xy, f0, axis)
 
 
 @settings(max_examples=8, deadline=None)
