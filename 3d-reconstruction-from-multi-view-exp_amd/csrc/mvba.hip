@@ -283,7 +283,7 @@ constexpr int PBS = 16;
 // the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
                                                    double *__restrict__ PB, int *__restrict__ flag,
-                                                   double *__restrict__ Ab, long long nAb, int *__restrict__ prog, int nprog) {
+                                                   double *__restrict__ Ab, long long nAb, int *__restrict__ prog, long long nprog) {
   // a block's 256 points are 18 KiB of PL and 32 KiB of PB, both contiguous: moved with coalesced
   // accesses through LDS (a thread reading its own 72-byte row / writing its own 128-byte line touches
   // 64 different lines per instruction)
@@ -693,6 +693,10 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
         const double2 e = reinterpret_cast<const double2 *>(lbuf)[it];
         w0 = kx0.x * pb[6] + kx1.x * pb[7] + kx2.x * pb[8] - e.x;
         w1 = kx0.y * pb[6] + kx1.y * pb[7] + kx2.y * pb[8] - e.y;
+        if (SLOTS) {  // a padding row gathers a real record (its range's first) next to the all-zero point row
+          w0 *= wgt;
+          w1 *= wgt;
+        }
       }
       const double2 s0v = lr[sel0], s1v = lr[sel1], s2v = lr[sel2];
       const double sx[3] = {s0v.x, al12 * s1v.x + bx1, al12 * s2v.x};
@@ -1038,7 +1042,7 @@ __device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc,
                                                  const double *__restrict__ PB, double c, double f0,
                                                  double *__restrict__ partial, int *__restrict__ head, int nR, int wpr,
                                                  const int *__restrict__ seg_end, int *__restrict__ prog, int nseg, int lag,
-                                                 long long *__restrict__ trace) {
+                                                 long long *__restrict__ trace, const long long *__restrict__ range_o0) {
   extern __shared__ char smem_pairs[];
   // which wave of which range: static (head == nullptr) block b IS wave b / nR of range b % nR; dynamic: the wave
   // reads the XCD it runs on and takes the next wave of a range of that XCD (r % 8 == XCC_ID), then of the others
@@ -1062,20 +1066,25 @@ __device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc,
   if (nsteps <= 0) return;  // (wave-uniform) a wave whose lists are all empty in this range: no units, nothing to write
   const long long beg = ((long long)d_y << 32) | (unsigned)d_x;
   const int *su = wunits + (size_t)bid * PSTEP;
+  // flags: bit 0 diagonal wave | bits 8..19 live waves of this (round, range) | bits 20..30 round
+  const int r = bid % nR, live = (flags >> 8) & 0xfff, round = (flags >> 20) & 0x7ff;
+  // the record indices of the step rows are RELATIVE to the range's first observation: the 32-bit byte offsets of the
+  // gathers then span a range's records (4 GiB = 33.5 M observations per range), not the scene's
+  const double2 *rec_r = rec + (size_t)as_const(range_o0)[r] * REC;
   SlotPace pace{nullptr, nullptr, 0, 0, 2, trace ? trace + 8 * (size_t)bid : nullptr};
-  if (prog) pace = SlotPace{seg_end + (size_t)bid * nseg, prog + (size_t)(bid % nR) * nseg * PACE_STRIDE, flags >> 8, nseg, lag, pace.trace};
+  if (prog) pace = SlotPace{seg_end + (size_t)bid * nseg, prog + ((size_t)round * nR + r) * nseg * PACE_STRIDE, live, nseg, lag, pace.trace};
   if (flags & 1)
-    schur_pairs_unit<true, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, partial, su, pace);
+    schur_pairs_unit<true, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec_r, PB, c, 1.0 / f0, partial, su, pace);
   else
-    schur_pairs_unit<false, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, partial, su, pace);
+    schur_pairs_unit<false, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec_r, PB, c, 1.0 / f0, partial, su, pace);
 }
 #define MVBA_SLOTS_ARGS                                                                                                  \
   const int4 *__restrict__ wdesc, const int *__restrict__ wunits, const int *__restrict__ it_k, const int *__restrict__ it_l, \
       const int *__restrict__ it_a, const double2 *__restrict__ rec, const double *__restrict__ PB, double c, double f0,  \
       double *__restrict__ partial, int *__restrict__ head, int nR, int wpr, const int *__restrict__ seg_end,            \
-      int *__restrict__ prog, int nseg, int lag, long long *__restrict__ trace
+      int *__restrict__ prog, int nseg, int lag, long long *__restrict__ trace, const long long *__restrict__ range_o0
 __global__ __launch_bounds__(64, 3) void k_schur_slots(MVBA_SLOTS_ARGS) {
-  schur_slots_wave(wdesc, wunits, it_k, it_l, it_a, rec, PB, c, f0, partial, head, nR, wpr, seg_end, prog, nseg, lag, trace);
+  schur_slots_wave(wdesc, wunits, it_k, it_l, it_a, rec, PB, c, f0, partial, head, nR, wpr, seg_end, prog, nseg, lag, trace, range_o0);
 }
 
 // One thread per element of a pair's block: the pair's unit partials in unit order -> packed strips.
@@ -2290,7 +2299,7 @@ __device__ __forceinline__ int idx_pair_id(int k, int l, int m) { return k * m -
 template <bool GLOBAL>
 __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_count(long long N, int m, int P, const long long *__restrict__ pt_ptr,
                                                               const int *__restrict__ cam_idx, int chunk,
-                                                              int *__restrict__ hist) {
+                                                              int *__restrict__ hist, const int *__restrict__ order) {
   extern __shared__ int s_hist_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
@@ -2300,7 +2309,8 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_count(long long N, int m
     wave_sync();
   }
   const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
-  for (long long a = a0; a < a1; ++a) {
+  for (long long ai = a0; ai < a1; ++ai) {
+    const long long a = order ? order[ai] : ai;  // (the sweep order of the points: see `point_order` in mvba_create)
     const long long o0 = pt_ptr[a];
     const int d = (int)(pt_ptr[a + 1] - o0);
     for (int i = 0; i < d; ++i) {
@@ -2337,7 +2347,8 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m,
                                                              const int *__restrict__ cam_idx, int chunk,
                                                              int *__restrict__ hist, const int *__restrict__ S,
                                                              const int *__restrict__ vp_ptr, const long long *__restrict__ vp_off,
-                                                             int *__restrict__ it_k, int *__restrict__ it_l, int *__restrict__ it_a) {
+                                                             int *__restrict__ it_k, int *__restrict__ it_l, int *__restrict__ it_a,
+                                                             const int *__restrict__ order) {
   extern __shared__ int s_hist_all[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long w = (long long)blockIdx.x * IDX_WAVES + wv;
@@ -2347,7 +2358,8 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m,
     wave_sync();
   }
   const long long a0 = w * chunk, a1 = min(N, a0 + chunk);
-  for (long long a = a0; a < a1; ++a) {
+  for (long long ai = a0; ai < a1; ++ai) {
+    const long long a = order ? order[ai] : ai;
     const long long o0 = pt_ptr[a];
     const int d = (int)(pt_ptr[a + 1] - o0);
     for (int i = 0; i < d; ++i) {
@@ -2375,7 +2387,7 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_idx_fill(long long N, int m,
 
 // lo[v][r] = first item of list v whose point is >= range_lo[r]  (r = 0 .. nR: the last column is the list's end)
 __global__ void k_idx_bounds(int VP, int nR, const long long *__restrict__ vp_off, const long long *__restrict__ range_lo,
-                             const int *__restrict__ it_a, long long *__restrict__ lo) {
+                             const int *__restrict__ it_a, long long *__restrict__ lo, const int *__restrict__ rank) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)VP * (nR + 1)) return;
   const int v = (int)(t / (nR + 1)), r = (int)(t - (long long)v * (nR + 1));
@@ -2383,15 +2395,16 @@ __global__ void k_idx_bounds(int VP, int nR, const long long *__restrict__ vp_of
   const long long key = range_lo[r];
   while (b < e) {  // lower_bound
     const long long mid = (b + e) >> 1;
-    if (it_a[mid] < key) b = mid + 1;
+    if ((rank ? rank[it_a[mid]] : it_a[mid]) < key) b = mid + 1;  // (a list is ascending in sweep order; ranges are contiguous in it)
     else e = mid;
   }
   lo[t] = b;
 }
 
 // The bounded-skew merge of one wave's 21 lists (see k_schur_slots), lane = slot.  FILL = false: count the steps.
-// FILL = true: write the step-major rows, the pacing table (steps taken when the slowest slot leaves a segment) and
-// the padding rows (record n_obs, point N: the all-zero rows).
+// FILL = true: write the step-major rows (record indices RELATIVE to the range's first observation), the pacing table
+// (steps taken when the slowest slot leaves a segment) and the padding rows (`pad_obs` = 0: the range's first record,
+// any finite one will do, times `pad_pt` = N: the all-zero point row).
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int nSeg, long long skew, long long segG,
                                                   const long long *__restrict__ sl_beg, const int *__restrict__ sl_len,
@@ -2399,7 +2412,7 @@ __global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int
                                                   const int *__restrict__ it_l, const int *__restrict__ it_a,
                                                   const long long *__restrict__ w_beg, int pad_obs, int pad_pt,
                                                   int *__restrict__ w_steps, int *__restrict__ st_k, int *__restrict__ st_l,
-                                                  int *__restrict__ st_a, int *__restrict__ seg_end) {
+                                                  int *__restrict__ st_a, int *__restrict__ seg_end, const long long *__restrict__ pkey) {
   const long long b = blockIdx.x;
   const int lane = threadIdx.x;
   const bool slot = lane < PSTEP;
@@ -2409,8 +2422,11 @@ __global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int
   const long long base = FILL ? w_beg[b] : 0;
   constexpr long long NONE = 1LL << 40;
   int steps = 0, sg = 0;
+  // an item's key = where its point sits in the sweep, in observations (pkey[a] = observations of the points swept
+  // before a; with the natural order that is a's first observation); the k-side record index is what goes into the row
   // two keys ahead in registers: the next step's key never waits for a load issued in this step
-  long long k0 = cur < end ? it_k[cur] : NONE, k1 = cur + 1 < end ? it_k[cur + 1] : NONE;
+  auto key_at = [&](long long c) -> long long { return pkey[it_a[c]]; };
+  long long k0 = cur < end ? key_at(cur) : NONE, k1 = cur + 1 < end ? key_at(cur + 1) : NONE;
   while (true) {
     long long lo = k0;
 #pragma unroll
@@ -2421,14 +2437,14 @@ __global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int
     const bool take = k0 < NONE && k0 <= lo + skew;
     if (FILL && slot) {
       const long long o = (base + steps) * PSTEP + lane;
-      st_k[o] = take ? (int)k0 : pad_obs;
-      st_l[o] = take ? it_l[cur] : pad_obs;
+      st_k[o] = take ? (int)(it_k[cur] - o_lo) : pad_obs;  // record indices relative to the range's first observation
+      st_l[o] = take ? (int)(it_l[cur] - o_lo) : pad_obs;
       st_a[o] = take ? it_a[cur] : pad_pt;
     }
     if (take) {
       ++cur;
       k0 = k1;
-      k1 = cur + 1 < end ? it_k[cur + 1] : NONE;
+      k1 = cur + 1 < end ? key_at(cur + 1) : NONE;
     }
     ++steps;
   }
@@ -2470,7 +2486,8 @@ struct mvba_handle {
   long long slot_skew = 12288;        // bounded skew of the slot form's step merge, in observations
   long long slot_window = 1LL << 40;  // ... and the window in which all waves of a range take equally many steps (off)
   long long n_items = 0, n_items_offdiag = 0, n_slot_items = 0;
-  int n_units = 0, rccl_version = 0, q_max = 0, n_waves = 0, slot_nR = 8, slot_nseg = 0;
+  int n_units = 0, rccl_version = 0, q_max = 0, n_waves = 0, slot_nR = 8, slot_nseg = 0, slot_rounds = 1, slot_groups = 1;
+  long long *d_range_o0 = nullptr;    // slot form: first observation of every point range (the record base of its waves)
   long long slot_seg = 8192;          // pacing segment of the slot form, in observations
   bool slot_pace = true;
   int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
@@ -2881,7 +2898,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         TRYH(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)idx_waves * P, h->stream));
       }
       hipLaunchKernelGGL(hist_lds ? k_idx_count<false> : k_idx_count<true>, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), idx_lds,
-                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist);
+                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, (const int *)nullptr);
       hipLaunchKernelGGL(k_idx_scan, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, h->stream, (int)P, (int)idx_waves, d_hist, d_cnt);
       TRYH(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(long long) * P, hipMemcpyDeviceToHost, h->stream));
       TRYH(hipStreamSynchronize(h->stream));
@@ -2917,45 +2934,196 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       vp_ptr[q + 1] = vp_ptr[q] + S[q];
     }
     const int VP = vp_ptr[P];
-    // ---- which form of the kernel: the slot-resident one (k_schur_slots) needs all lists of a point range resident on
-    // one XCD at once -- 9 waves per CU (LDS) x n_cu / 8 CUs x 21 slots = 6048 lists: up to 100 cameras at 10 %
-    // visibility (4950 pairs + ~1000 sub-lists of the diagonal pairs); beyond that the unit form runs
-    int n_off_lists = 0, n_diag_lists = 0;
-    for (int k = 0; k < m; ++k)
-      for (int l = k; l < m; ++l) (k == l ? n_diag_lists : n_off_lists) += S[pair_id(k, l)];
-    const int wpr = (n_off_lists + PSTEP - 1) / PSTEP + (n_diag_lists + PSTEP - 1) / PSTEP;  // waves per range
+    // ---- which form of the kernel: the slot-resident one (k_schur_slots) needs all lists that sweep a point range
+    // TOGETHER resident on one XCD at once -- 9 waves per CU (LDS) x n_cu / 8 CUs x 21 slots = 6048 lists.  Up to ~100
+    // cameras at 10 % visibility (4950 pairs + ~1000 sub-lists of the diagonal pairs) that is every list: one ROUND.
+    // Beyond that the cameras are cut into `ng` groups and a round holds the pairs of one group pair (g1 <= g2): its
+    // waves sweep the range's points together and touch only the records of the two groups' cameras, so the footprint
+    // per round still fits the L2; the rounds of a range follow each other inside ONE launch (the blocks of round
+    // r + 1 start as the waves of round r finish).  A record is then read once per round its camera's group is in
+    // (ng + 1 times) instead of once per unit that needs it (the unit form: ~16 times from beyond the L2 at m = 500).
     int n_cu_dev = 256;
     hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, h->device);
     const int xcd_waves = std::max(1, n_cu_dev / 8) * (160 * 1024 / SLOT_LDS);  // 9 waves of 17,136 B of LDS per CU
+    int ng = 1, G = m, max_round_waves = 0;
+    auto round_waves = [&](int G_, int g1, int g2) {  // waves (of 21 lists) of round (g1, g2): diagonal + off-diagonal
+      long long ld = 0, lo = 0;
+      for (int k = g1 * G_; k < std::min(m, (g1 + 1) * G_); ++k) {
+        if (g1 == g2) ld += S[pair_id(k, k)];
+        for (int l = std::max(k + 1, g2 * G_); l < std::min(m, (g2 + 1) * G_); ++l) lo += S[pair_id(k, l)];
+      }
+      return (int)((ld + PSTEP - 1) / PSTEP + (lo + PSTEP - 1) / PSTEP);
+    };
+    if (const char *ev = getenv("MVBA_SLOT_GROUPS")) ng = std::max(1, std::min(m, atoi(ev)));
+    for (;; ++ng) {
+      G = (m + ng - 1) / ng;
+      max_round_waves = 0;
+      for (int g1 = 0; g1 * G < m; ++g1)
+        for (int g2 = g1; g2 * G < m; ++g2) max_round_waves = std::max(max_round_waves, round_waves(G, g1, g2));
+      if (max_round_waves <= xcd_waves || G == 1) break;
+    }
+    ng = (m + G - 1) / G;  // (groups that hold a camera)
     // (below ~4 M items the launch is all prologue and pacing: the unit form's many short waves win -- config 2,
     // 10k points x 20 cameras: 0.095 against 0.124 ms; equal at 5.5 M items; MVBA_SCHUR=slots keeps the slot form)
     const bool slots_forced = getenv("MVBA_SCHUR") && !strcmp(getenv("MVBA_SCHUR"), "slots");
-    if (h->schur_mode == SCHUR_SLOTS && (wpr > xcd_waves || (std::max(nobs, N) + 1) * 128LL >= (1LL << 32) || h->force_big ||
-                                         (T < 4000000 && !slots_forced)))
+    // (the gathers use 32-bit byte offsets: point rows from the array's start, records from their RANGE's first
+    // observation -- checked below, once the ranges are known)
+    // More than one round pays only while a list keeps enough items per L2 window for its wave's 21 lists to march in
+    // step: at config 4 (500 cameras, 5 %: 390 items per list and range, ~10 per L2 window) the rounds cut the fabric
+    // traffic 2.3x (742 M -> 328 M lines per launch) and still lose to the unit form, 18.1 against 14.3 ms -- 19-40 % padding
+    // rows and the pacing waits of 250 waves on lists that sparse (profiles/r04_sweep_c4_rounds.txt).  MVBA_SCHUR=slots forces them.
+    long long min_round_list = 1LL << 40;  // items per list and range, thinnest round
+    if (ng > 1) {
+      long long lists_total = 0;
+      for (long long q = 0; q < P; ++q) lists_total += S[q];
+      min_round_list = T / std::max<long long>(1, lists_total) / 8;
+    }
+    // ... and with denser lists as well (1 M points x 200 cameras x 10 %, 1250 items per list and range, three rounds: 8.9
+    // against 6.3 ms; 2 M x 150 x 10 %: 8.6 against 7.4; 1 M x 300 x 5 %: 5.3 against 4.3 -- profiles/r04_sweep_rounds_crossover.txt):
+    // more than one round runs only on request (MVBA_SCHUR=slots, or MVBA_SLOT_ROUND_MIN=<items per list and range>).
+    long long round_min_items = 1LL << 40;
+    if (const char *ev = getenv("MVBA_SLOT_ROUND_MIN")) round_min_items = std::max(0LL, atoll(ev));
+    if (h->schur_mode == SCHUR_SLOTS && (max_round_waves > xcd_waves || (N + 1) * 128LL >= (1LL << 32) || h->force_big || ng > 2047 ||
+                                         ((T < 4000000 || (ng > 1 && min_round_list < round_min_items)) && !slots_forced)))
       h->schur_mode = SCHUR_PAIRS;
-    const bool slots = h->schur_mode == SCHUR_SLOTS;
     // point ranges.  Unit form: long runs for big problems, but small ones still get ~4096 units of >= 128 items.
     // Slot form: 8 ranges (one per XCD) -- 8 j while j ranges' worth of waves fit an XCD and a list keeps >= 64 items.
-    int nR;
-    if (slots) {
-      const long long j = std::max<long long>(1, std::min<long long>(xcd_waves / wpr, target / (8 * 64)));
-      nR = (int)(8 * std::min<long long>(j, 8));
-    } else {
-      const long long nR_big = (target + unit_items / 2) / unit_items, nR_fill = std::min<long long>((4096 + VP - 1) / VP, target / 128);
-      nR = (int)std::max<long long>(1, std::min<long long>(64, std::max(nR_big, nR_fill)));
-    }
-    std::vector<long long> range_lo(nR + 1);
-    if (slots) {  // equal ITEM counts: the ranges run side by side, one per XCD
-      std::vector<long long> pre(N + 1, 0);
-      for (long long a = 0; a < N; ++a) {
-        const long long d = p->pt_ptr[a + 1] - p->pt_ptr[a];
-        pre[a + 1] = pre[a] + d * (d + 1) / 2;
+    int nR = 1;
+    std::vector<long long> range_lo;
+    auto make_ranges = [&]() {
+      if (h->schur_mode == SCHUR_SLOTS) {
+        const long long j = std::max<long long>(1, std::min<long long>(xcd_waves / std::max(1, max_round_waves), target / (8 * 64)));
+        nR = (int)(8 * std::min<long long>(j, 8));
+        range_lo.assign(nR + 1, 0);
+        // equal ITEM counts: the ranges run side by side, one per XCD
+        std::vector<long long> pre(N + 1, 0);
+        for (long long a = 0; a < N; ++a) {
+          const long long d = p->pt_ptr[a + 1] - p->pt_ptr[a];
+          pre[a + 1] = pre[a] + d * (d + 1) / 2;
+        }
+        for (int r = 0; r <= nR; ++r)
+          range_lo[r] = std::lower_bound(pre.begin(), pre.end(), (long long)((__int128)pre[N] * r / nR)) - pre.begin();
+        range_lo[0] = 0; range_lo[nR] = N;
+      } else {
+        const long long nR_big = (target + unit_items / 2) / unit_items, nR_fill = std::min<long long>((4096 + VP - 1) / VP, target / 128);
+        nR = (int)std::max<long long>(1, std::min<long long>(64, std::max(nR_big, nR_fill)));
+        range_lo.assign(nR + 1, 0);
+        for (int r = 0; r <= nR; ++r) range_lo[r] = (long long)((__int128)N * r / nR);
       }
-      for (int r = 0; r <= nR; ++r)
-        range_lo[r] = std::lower_bound(pre.begin(), pre.end(), (long long)((__int128)pre[N] * r / nR)) - pre.begin();
-      range_lo[0] = 0; range_lo[nR] = N;
-    } else {
-      for (int r = 0; r <= nR; ++r) range_lo[r] = (long long)((__int128)N * r / nR);
+    };
+    make_ranges();
+    if (h->schur_mode == SCHUR_SLOTS) {
+      long long widest = 0;
+      for (int r = 0; r < nR; ++r) widest = std::max<long long>(widest, p->pt_ptr[range_lo[r + 1]] - p->pt_ptr[range_lo[r]]);
+      if ((widest + 1) * 128LL >= (1LL << 32)) {  // a range's records span 4 GiB: the unit form's 64-bit-offset build
+        h->schur_mode = SCHUR_PAIRS;
+        make_ranges();
+      }
+    }
+    const bool slots = h->schur_mode == SCHUR_SLOTS;
+    // ---- sweep order of the points inside a range (slot form).  The 21 lists of a wave march through the range in step
+    // and a slot whose next item lies beyond the skew window idles: with the points in their natural (random) order a
+    // list is a Poisson process -- 12.4 % padding rows at config 3, and the waves' steps per pacing segment scatter as
+    // widely, which is what they wait for at the crossings.  Any order is as good for the kernel (a record is a line of
+    // its own, the sums are per slot), so the index is built over a LOW-DISCREPANCY order: inside blocks of 8192 points
+    // the next point is the best of `cand` random candidates by the summed deficit of its pairs (expected minus actual
+    // count so far) -- the variance / mean of a pair's count per 2000-point window falls from 0.9 to ~0.25.  Deterministic
+    // (fixed seeds), host threads by block; skipped when too dear (candidates x items; config 4's shard: 325 pairs per
+    // point) and with MVBA_POINT_ORDER=natural.  order[i] = point at sweep position i, rank = its inverse, pkey[a] =
+    // observations of the points swept before a, counted from the scene's start like a record index.
+    std::vector<int> order, rank;
+    std::vector<long long> pkey(N, 0);
+    {
+      const char *po = getenv("MVBA_POINT_ORDER");
+      int cand = 32;
+      if (const char *ev = getenv("MVBA_POINT_ORDER_CAND")) cand = std::max(1, atoi(ev));
+      bool reorder = slots && N > 0 && !(po && !strcmp(po, "natural"));
+      if (reorder && (double)T * cand > 8e9 && !(po && !strcmp(po, "greedy"))) reorder = false;
+      if (reorder) {
+        order.resize(N); rank.resize(N);
+        constexpr long long OB = 8192;
+        std::vector<std::pair<long long, long long>> blocks;
+        for (int r = 0; r < nR; ++r)
+          for (long long b0 = range_lo[r]; b0 < range_lo[r + 1]; b0 += OB) blocks.push_back({b0, std::min(range_lo[r + 1], b0 + OB)});
+        std::atomic<size_t> next{0};
+        const int nt = (int)std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)blocks.size()}));
+        auto work = [&]() {
+          std::vector<int> count(P);
+          std::vector<double> R;
+          for (;;) {
+            const size_t bi = next.fetch_add(1);
+            if (bi >= blocks.size()) break;
+            const long long b0 = blocks[bi].first, b1 = blocks[bi].second, nb = b1 - b0;
+            std::fill(count.begin(), count.end(), 0);
+            R.assign(nb, 0.0);
+            int *ord = order.data() + b0;
+            for (long long i = 0; i < nb; ++i) {
+              ord[i] = (int)(b0 + i);
+              const int *cb = p->cam_idx + p->pt_ptr[b0 + i];
+              const int d = (int)(p->pt_ptr[b0 + i + 1] - p->pt_ptr[b0 + i]);
+              double rs = 0.0;
+              for (int x = 0; x < d; ++x)
+                for (int y = x; y < d; ++y) rs += (double)cnt[pair_id(cb[x], cb[y])];
+              R[i] = rs / (double)N;  // expected arrivals of this point's pairs per point swept
+            }
+            unsigned long long rng = 0x9E3779B97F4A7C15ull * (bi + 1);
+            for (long long t = 0; t < nb; ++t) {
+              long long best = t;
+              double best_s = -1e300;
+              for (int c = 0; c < cand; ++c) {
+                rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                const long long j = t + (long long)(rng % (unsigned long long)(nb - t));
+                const long long a = ord[j];
+                const int *cb = p->cam_idx + p->pt_ptr[a];
+                const int d = (int)(p->pt_ptr[a + 1] - p->pt_ptr[a]);
+                long long have = 0;
+                for (int x = 0; x < d; ++x) {
+                  const int *row = count.data() + pair_id(cb[x], cb[x]) - cb[x];
+                  for (int y = x; y < d; ++y) have += row[cb[y]];
+                }
+                const double sc = (double)t * R[a - b0] - (double)have;
+                if (sc > best_s) { best_s = sc; best = j; }
+              }
+              std::swap(ord[t], ord[best]);
+              const long long a = ord[t];
+              const int *cb = p->cam_idx + p->pt_ptr[a];
+              const int d = (int)(p->pt_ptr[a + 1] - p->pt_ptr[a]);
+              for (int x = 0; x < d; ++x) {
+                int *row = count.data() + pair_id(cb[x], cb[x]) - cb[x];
+                for (int y = x; y < d; ++y) row[cb[y]]++;
+              }
+            }
+          }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        for (long long i = 0; i < N; ++i) rank[order[i]] = (int)i;
+      }
+      long long run = 0;
+      for (long long i = 0; i < N; ++i) {
+        const long long a = order.empty() ? i : order[i];
+        pkey[a] = run;
+        run += p->pt_ptr[a + 1] - p->pt_ptr[a];
+      }
+    }
+    lap("point order");
+    int *d_order = nullptr, *d_rank = nullptr;
+    long long *d_pkey = nullptr;
+    if (dev_build && slots) {
+      TRY(dmalloc(&d_pkey, (size_t)N));
+      TRYH(hipMemcpyAsync(d_pkey, pkey.data(), sizeof(long long) * N, hipMemcpyHostToDevice, h->stream));
+      if (!order.empty()) {
+        TRY(dmalloc(&d_order, (size_t)N)); TRY(dmalloc(&d_rank, (size_t)N));
+        TRYH(hipMemcpyAsync(d_order, order.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+        TRYH(hipMemcpyAsync(d_rank, rank.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+        // the per-wave start ranks again, in sweep order (the totals are the same)
+        if (!hist_lds) TRYH(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)idx_waves * P, h->stream));
+        hipLaunchKernelGGL(hist_lds ? k_idx_count<false> : k_idx_count<true>, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), idx_lds,
+                           h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_order);
+        hipLaunchKernelGGL(k_idx_scan, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, h->stream, (int)P, (int)idx_waves, d_hist, d_cnt);
+      }
     }
     std::vector<long long> vp_off(VP + 1, 0);
     for (long long q = 0; q < P; ++q)
@@ -2966,9 +3134,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     int *d_pk = nullptr, *d_pl = nullptr, *d_pa = nullptr, *d_S = nullptr, *d_vp_ptr = nullptr;
     long long *d_vp_off = nullptr;
     auto free_dev_tmp = [&]() {
-      for (void *q : {(void *)d_hist, (void *)d_cnt, (void *)d_pk, (void *)d_pl, (void *)d_pa, (void *)d_S, (void *)d_vp_ptr, (void *)d_vp_off})
+      for (void *q : {(void *)d_hist, (void *)d_cnt, (void *)d_pk, (void *)d_pl, (void *)d_pa, (void *)d_S, (void *)d_vp_ptr, (void *)d_vp_off,
+                      (void *)d_order, (void *)d_rank, (void *)d_pkey})
         if (q) hipFree(q);
-      d_hist = nullptr; d_cnt = nullptr; d_pk = d_pl = d_pa = d_S = d_vp_ptr = nullptr; d_vp_off = nullptr;
+      d_hist = nullptr; d_cnt = nullptr; d_pk = d_pl = d_pa = d_S = d_vp_ptr = d_order = d_rank = nullptr; d_vp_off = d_pkey = nullptr;
     };
     if (dev_items) {
       TRY(dmalloc(&d_pk, (size_t)T)); TRY(dmalloc(&d_pl, (size_t)T)); TRY(dmalloc(&d_pa, (size_t)T));
@@ -2977,7 +3146,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       TRYH(hipMemcpyAsync(d_vp_ptr, vp_ptr.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, h->stream));
       TRYH(hipMemcpyAsync(d_vp_off, vp_off.data(), sizeof(long long) * (VP + 1), hipMemcpyHostToDevice, h->stream));
       hipLaunchKernelGGL(hist_lds ? k_idx_fill<false> : k_idx_fill<true>, dim3((unsigned)(idx_waves / IDX_WAVES)), dim3(64 * IDX_WAVES), idx_lds,
-                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_S, d_vp_ptr, d_vp_off, d_pk, d_pl, d_pa);
+                         h->stream, N, m, (int)P, h->d_pt_ptr, h->d_cam, idx_chunk, d_hist, d_S, d_vp_ptr, d_vp_off, d_pk, d_pl, d_pa,
+                         (const int *)d_order);
       TRYH(hipGetLastError());
     } else {
       if (dev_build) { hipFree(d_hist); hipFree(d_cnt); d_hist = nullptr; d_cnt = nullptr; }
@@ -2985,7 +3155,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     {
       std::vector<long long> run(P, 0);
       on_threads([&](int tid) {
-        for (long long a = 0; a < N; ++a) {
+        for (long long ai = 0; ai < N; ++ai) {
+          const long long a = order.empty() ? ai : order[ai];
           const long long o0 = p->pt_ptr[a];
           const int *cb = p->cam_idx + o0;
           const int d = (int)(p->pt_ptr[a + 1] - o0);
@@ -3013,7 +3184,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       TRY(dmalloc(&d_rl, (size_t)nR + 1)); TRY(dmalloc(&d_lo, (size_t)VP * (nR + 1)));
       TRYH(hipMemcpyAsync(d_rl, range_lo.data(), sizeof(long long) * (nR + 1), hipMemcpyHostToDevice, h->stream));
       const long long nt = (long long)VP * (nR + 1);
-      hipLaunchKernelGGL(k_idx_bounds, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, VP, nR, d_vp_off, d_rl, d_pa, d_lo);
+      hipLaunchKernelGGL(k_idx_bounds, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, VP, nR, d_vp_off, d_rl, d_pa, d_lo, (const int *)d_rank);
       lo_tab.resize(nt);
       TRYH(hipMemcpyAsync(lo_tab.data(), d_lo, sizeof(long long) * nt, hipMemcpyDeviceToHost, h->stream));
       TRYH(hipStreamSynchronize(h->stream));
@@ -3027,8 +3198,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
           const int v = vp_ptr[q] + sI;
           const int *b = it_a.data() + (dev_items ? 0 : vp_off[v]), *e = it_a.data() + (dev_items ? 0 : vp_off[v + 1]);
           for (int r = 0; r < nR; ++r) {
-            const long long lo = dev_items ? lo_tab[(size_t)v * (nR + 1) + r] : std::lower_bound(b, e, range_lo[r]) - it_a.data();
-            const long long hi = dev_items ? lo_tab[(size_t)v * (nR + 1) + r + 1] : std::lower_bound(b, e, range_lo[r + 1]) - it_a.data();
+            auto before = [&](int a, long long key) { return (rank.empty() ? (long long)a : (long long)rank[a]) < key; };
+            const long long lo = dev_items ? lo_tab[(size_t)v * (nR + 1) + r] : std::lower_bound(b, e, range_lo[r], before) - it_a.data();
+            const long long hi = dev_items ? lo_tab[(size_t)v * (nR + 1) + r + 1] : std::lower_bound(b, e, range_lo[r + 1], before) - it_a.data();
             if (hi <= lo) continue;
             uid[(size_t)v * nR + r] = (int)units.size();
             units.push_back(make_int4((int)(lo & 0xffffffffLL), (int)(lo >> 32), (int)(hi - lo), (k << 16) | l));
@@ -3038,42 +3210,56 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     unit_ptr[P] = (int)units.size();
     lap("units");
     if (slots) {
-      // ---- waves of 21 lists (off-diagonal lists first, then the diagonal pairs' sub-lists), every wave once per range
-      std::vector<int> lists_off, lists_diag;  // list ids v = vp_ptr[pair] + sub-list
-      for (int k = 0; k < m; ++k)
-        for (int l = k; l < m; ++l) {
-          const long long q = pair_id(k, l);
-          for (int sI = 0; sI < S[q]; ++sI) (k == l ? lists_diag : lists_off).push_back(vp_ptr[q] + sI);
+      // ---- waves of 21 lists, every wave once per range, round by round (one round up to ~100 cameras); inside a round
+      // the diagonal pairs' sub-lists come FIRST: a CU's SIMDs arbitrate by age, the blocks dispatched last share a
+      // SIMD three ways as its youngest wave and fall behind -- and a diagonal step is the dearer one
+      std::vector<int> wl;                    // [wave of a range][21] list ids v = vp_ptr[pair] + sub-list, -1: none
+      std::vector<int> w_round, w_isdiag;     // per wave of a range
+      int n_rounds = 0;
+      for (int g1 = 0; g1 * G < m; ++g1)
+        for (int g2 = g1; g2 * G < m; ++g2, ++n_rounds) {
+          std::vector<int> ld, lo;
+          for (int k = g1 * G; k < std::min(m, (g1 + 1) * G); ++k) {
+            if (g1 == g2)
+              for (int sI = 0; sI < S[pair_id(k, k)]; ++sI) ld.push_back(vp_ptr[pair_id(k, k)] + sI);
+            for (int l = std::max(k + 1, g2 * G); l < std::min(m, (g2 + 1) * G); ++l)
+              for (int sI = 0; sI < S[pair_id(k, l)]; ++sI) lo.push_back(vp_ptr[pair_id(k, l)] + sI);
+          }
+          for (const std::vector<int> *src : {&ld, &lo})
+            for (size_t first = 0; first < src->size(); first += PSTEP) {
+              for (int sl = 0; sl < PSTEP; ++sl) wl.push_back(first + sl < src->size() ? (*src)[first + sl] : -1);
+              w_round.push_back(n_rounds);
+              w_isdiag.push_back(src == &ld);
+            }
         }
-      const int w_off = (int)((lists_off.size() + PSTEP - 1) / PSTEP);
+      const int wpr = (int)w_round.size();    // waves per range
       const long long n_waves = (long long)wpr * nR;
       wdesc.assign(n_waves, make_int4(0, 0, 0, 0));
       wunits.assign((size_t)n_waves * PSTEP, -1);
       std::vector<long long> w_steps(n_waves, 0), w_beg(n_waves + 1, 0);
       // block b = nR w + r: wave w of range r runs on XCD r % 8
-      // (the diagonal waves come FIRST: a CU's SIMDs arbitrate by age, the blocks dispatched last share a SIMD three
-      // ways as its youngest wave and fall behind -- and a diagonal step is the dearer one)
-      const int w_diag = wpr - w_off;
       auto wave_lists = [&](long long b, int *vs) {  // the 21 list ids of block b (-1: none); returns the range
-        const int w = (int)(b / nR);
-        const bool dg = w < w_diag;
-        const std::vector<int> &src = dg ? lists_diag : lists_off;
-        const size_t first = (size_t)(dg ? w : w - w_diag) * PSTEP;
-        for (int sl = 0; sl < PSTEP; ++sl) vs[sl] = first + sl < src.size() ? src[first + sl] : -1;
+        const int *src = wl.data() + (size_t)(b / nR) * PSTEP;
+        for (int sl = 0; sl < PSTEP; ++sl) vs[sl] = src[sl];
         return (int)(b % nR);
       };
+      auto round_range = [&](long long b) { return (size_t)w_round[b / nR] * nR + (size_t)(b % nR); };
+      // a round touches the records of 2 of ng camera groups only: its skew and pacing segments, counted in
+      // observations of the range, stretch accordingly (the footprint in the L2 is what they bound)
+      const long long stretch = std::max(1, ng / 2);
       // Bounded-skew merge of a wave's lists into steps (see k_schur_slots), window by window: the observations of a
       // range are cut into windows of `slot_window`, and every wave of the range is padded to the same number of
       // steps per window (the slowest wave's), so that all waves of an XCD reach a window boundary at the same step
       // index and cannot drift apart by more than their rate difference inside one window.
-      const long long skew = h->slot_skew, window = std::max<long long>(1, h->slot_window);
+      const long long skew = h->slot_skew * stretch, window = std::max<long long>(1, h->slot_window);
       int nWin = 1;
       for (int r = 0; r < nR; ++r)
         nWin = std::max<long long>(nWin, (p->pt_ptr[range_lo[r + 1]] - p->pt_ptr[range_lo[r]] + window - 1) / window);
       const bool equalize = h->slot_window < (1LL << 39);
-      std::vector<int> win_steps((size_t)n_waves * nWin, 0), win_max((size_t)nR * nWin, 0);
+      std::vector<int> win_steps((size_t)n_waves * nWin, 0), win_max((size_t)n_rounds * nR * nWin, 0);
       // pacing segments: seg_end[b][j] = steps wave b has taken when its slowest slot leaves segment j of the range
-      const long long segG = std::max<long long>(1, h->slot_seg);
+      // (no pacing, MVBA_SLOT_SEG=0: one segment -- the table has a row per wave and segment)
+      const long long segG = h->slot_pace ? std::max<long long>(1, h->slot_seg * stretch) : (1LL << 40);
       int nSeg = 1;
       for (int r = 0; r < nR; ++r)
         nSeg = std::max<long long>(nSeg, (p->pt_ptr[range_lo[r + 1]] - p->pt_ptr[range_lo[r]] + segG - 1) / segG);
@@ -3098,28 +3284,29 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
           long long ws = 0;
           while (true) {
             long long lo = -1;
+            auto key_of = [&](int sl) { return pkey[it_a[cur[sl]]]; };  // where the item's point sits in the sweep, in observations
             for (int sl = 0; sl < PSTEP; ++sl)
-              if (cur[sl] < end[sl] && it_k[cur[sl]] < limit && (lo < 0 || it_k[cur[sl]] < lo)) lo = it_k[cur[sl]];
+              if (cur[sl] < end[sl] && key_of(sl) < limit && (lo < 0 || key_of(sl) < lo)) lo = key_of(sl);
             if (fill && lo >= 0)
               while (sg < nSeg && lo >= o_lo + (sg + 1) * segG) seg_end[(size_t)b * nSeg + sg++] = (int)(steps + ws);
             if (lo < 0) break;
             for (int sl = 0; sl < PSTEP; ++sl) {
-              const bool take = cur[sl] < end[sl] && it_k[cur[sl]] < limit && it_k[cur[sl]] <= lo + skew;
+              const bool take = cur[sl] < end[sl] && key_of(sl) < limit && key_of(sl) <= lo + skew;
               if (fill) {
                 const long long o = (base + steps + ws) * PSTEP + sl;
-                if (take) { st_k[o] = it_k[cur[sl]]; st_l[o] = it_l[cur[sl]]; st_a[o] = it_a[cur[sl]]; }
-                else { st_k[o] = st_l[o] = (int)nobs; st_a[o] = (int)N; }  // the all-zero record and point row
+                if (take) { st_k[o] = (int)(it_k[cur[sl]] - o_lo); st_l[o] = (int)(it_l[cur[sl]] - o_lo); st_a[o] = it_a[cur[sl]]; }
+                else { st_k[o] = st_l[o] = 0; st_a[o] = (int)N; }  // the range's first record (any finite one) x the all-zero point row
               }
               if (take) ++cur[sl];
             }
             ++ws;
           }
           if (!fill) { win_steps[(size_t)b * nWin + j] = (int)ws; steps += ws; continue; }
-          const long long target_ws = equalize ? win_max[(size_t)r * nWin + j] : ws;
+          const long long target_ws = equalize ? win_max[round_range(b) * nWin + j] : ws;
           for (; ws < target_ws; ++ws)
             for (int sl = 0; sl < PSTEP; ++sl) {
               const long long o = (base + steps + ws) * PSTEP + sl;
-              st_k[o] = st_l[o] = (int)nobs; st_a[o] = (int)N;
+              st_k[o] = st_l[o] = 0; st_a[o] = (int)N;
             }
           steps += target_ws;
         }
@@ -3130,10 +3317,16 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       // device merge: the slots' list spans (from the units) go up, the step counts come back
       long long *d_slbeg = nullptr, *d_ro0 = nullptr, *d_wbeg = nullptr;
       int *d_sllen = nullptr, *d_wsteps = nullptr;
-      if (dev_items) {
-        std::vector<long long> sl_beg((size_t)n_waves * PSTEP, 0), ro0(nR);
-        std::vector<int> sl_len((size_t)n_waves * PSTEP, 0);
+      {  // first observation of every range: the merge kernels and k_schur_slots (its record base) read it
+        std::vector<long long> ro0(nR);
         for (int r = 0; r < nR; ++r) ro0[r] = p->pt_ptr[range_lo[r]];
+        TRY(dmalloc(&h->d_range_o0, (size_t)nR));
+        TRYH(hipMemcpy(h->d_range_o0, ro0.data(), sizeof(long long) * nR, hipMemcpyHostToDevice));
+        d_ro0 = h->d_range_o0;
+      }
+      if (dev_items) {
+        std::vector<long long> sl_beg((size_t)n_waves * PSTEP, 0);
+        std::vector<int> sl_len((size_t)n_waves * PSTEP, 0);
         for (long long b = 0; b < n_waves; ++b) {
           int vs[PSTEP];
           const int r = wave_lists(b, vs);
@@ -3145,14 +3338,13 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
             sl_len[(size_t)b * PSTEP + sl] = units[id].z;
           }
         }
-        TRY(dmalloc(&d_slbeg, sl_beg.size())); TRY(dmalloc(&d_sllen, sl_len.size())); TRY(dmalloc(&d_ro0, (size_t)nR));
+        TRY(dmalloc(&d_slbeg, sl_beg.size())); TRY(dmalloc(&d_sllen, sl_len.size()));
         TRY(dmalloc(&d_wsteps, (size_t)n_waves)); TRY(dmalloc(&d_wbeg, (size_t)n_waves + 1));
         TRYH(hipMemcpyAsync(d_slbeg, sl_beg.data(), sizeof(long long) * sl_beg.size(), hipMemcpyHostToDevice, h->stream));
         TRYH(hipMemcpyAsync(d_sllen, sl_len.data(), sizeof(int) * sl_len.size(), hipMemcpyHostToDevice, h->stream));
-        TRYH(hipMemcpyAsync(d_ro0, ro0.data(), sizeof(long long) * nR, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_idx_merge<false>, dim3((unsigned)n_waves), dim3(64), 0, h->stream, n_waves, nR, nSeg, skew, segG, d_slbeg, d_sllen,
-                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, (int)nobs, (int)N, d_wsteps, (int *)nullptr, (int *)nullptr, (int *)nullptr,
-                           (int *)nullptr);
+                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, 0, (int)N, d_wsteps, (int *)nullptr, (int *)nullptr, (int *)nullptr,
+                           (int *)nullptr, (const long long *)d_pkey);
         std::vector<int> ws32(n_waves);
         TRYH(hipMemcpyAsync(ws32.data(), d_wsteps, sizeof(int) * n_waves, hipMemcpyDeviceToHost, h->stream));
         TRYH(hipStreamSynchronize(h->stream));  // (sl_beg / sl_len / ro0 live until here)
@@ -3164,14 +3356,14 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       lap("slot merge (count)");
       for (long long b = 0; b < n_waves; ++b)
         for (int j = 0; j < nWin; ++j) {
-          int &mx = win_max[(size_t)(b % nR) * nWin + j];
+          int &mx = win_max[round_range(b) * nWin + j];
           mx = std::max(mx, win_steps[(size_t)b * nWin + j]);
         }
       for (long long b = 0; b < n_waves; ++b) {
         long long t = 0;
         bool any = false;
         for (int j = 0; j < nWin; ++j) {
-          t += equalize ? win_max[(size_t)(b % nR) * nWin + j] : win_steps[(size_t)b * nWin + j];
+          t += equalize ? win_max[round_range(b) * nWin + j] : win_steps[(size_t)b * nWin + j];
           any |= win_steps[(size_t)b * nWin + j] > 0;
         }
         w_steps[b] = any ? t : 0;  // a wave without any item does not run at all
@@ -3185,10 +3377,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
         TRY(dmalloc(&h->d_seg_end, seg_end.size()));
         TRYH(hipMemcpyAsync(d_wbeg, w_beg.data(), sizeof(long long) * (n_waves + 1), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_idx_merge<true>, dim3((unsigned)n_waves), dim3(64), 0, h->stream, n_waves, nR, nSeg, skew, segG, d_slbeg, d_sllen,
-                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, (int)nobs, (int)N, d_wsteps, h->d_it_k, h->d_it_l, h->d_it_a, h->d_seg_end);
+                           d_ro0, d_pk, d_pl, d_pa, d_wbeg, 0, (int)N, d_wsteps, h->d_it_k, h->d_it_l, h->d_it_a, h->d_seg_end, (const long long *)d_pkey);
         TRYH(hipGetLastError());
         TRYH(hipStreamSynchronize(h->stream));
-        for (void *q : {(void *)d_slbeg, (void *)d_sllen, (void *)d_ro0, (void *)d_wsteps, (void *)d_wbeg}) hipFree(q);
+        for (void *q : {(void *)d_slbeg, (void *)d_sllen, (void *)d_wsteps, (void *)d_wbeg}) hipFree(q);
         free_dev_tmp();
         h->index_on_device = true;
       } else {
@@ -3199,20 +3391,22 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       });
       }
       lap("slot merge (fill)");
-      const int w_off_ = w_off;
-      std::vector<int> live(nR, 0);  // waves of a range that run at all: what a pacing counter has to reach
-      for (long long b = 0; b < n_waves; ++b) live[b % nR] += w_steps[b] > 0;
+      std::vector<int> live((size_t)n_rounds * nR, 0);  // waves of a (round, range) that run at all: what a pacing counter has to reach
+      for (long long b = 0; b < n_waves; ++b) live[round_range(b)] += w_steps[b] > 0;
       for (long long b = 0; b < n_waves; ++b) {
         const long long beg = w_beg[b] * PSTEP;
+        // flags: bit 0 diagonal wave | bits 8..19 live waves of its (round, range) | bits 20..30 round
         wdesc[b] = make_int4((int)(beg & 0xffffffffLL), (int)(beg >> 32), (int)w_steps[b],
-                             ((int)(b / nR) < wpr - w_off_ ? 1 : 0) | (live[b % nR] << 8));
+                             (w_isdiag[b / nR] ? 1 : 0) | (live[round_range(b)] << 8) | (w_round[b / nR] << 20));
       }
+      h->slot_rounds = n_rounds;
+      h->slot_groups = ng;
       h->n_waves = (int)n_waves;
       h->slot_nR = nR;
 #ifdef MVBA_SLOT_TRACE
       if (const char *ev = getenv("MVBA_SLOT_DUMP"))  // diagnostic build: the pacing table (steps at each segment boundary)
         if (FILE *f = fopen(ev, "wb")) {
-          const int hdr[4] = {(int)n_waves, nSeg, nR, wpr};
+          const int hdr[4] = {(int)n_waves, nSeg, nR, wpr};  // (pacing is per (round, range): MVBA_SLOT_GROUPS=1 scenes for the replay tool)
           fwrite(hdr, sizeof(int), 4, f);
           fwrite(seg_end.data(), sizeof(int), seg_end.size(), f);
           fclose(f);
@@ -3318,7 +3512,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (getenv("MVBA_SLOT_TRACE")) { TRY(dmalloc(&h->d_trace, 8 * std::max<size_t>(1, wdesc.size()))); TRYH(hipMemset(h->d_trace, 0, 64 * std::max<size_t>(1, wdesc.size()))); }
 #endif
     if (!h->index_on_device) TRY(dmalloc(&h->d_seg_end, seg_end.size()));
-    TRY(dmalloc(&h->d_prog, (size_t)h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
+    TRY(dmalloc(&h->d_prog, (size_t)h->slot_rounds * h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
     if (!seg_end.empty() && !h->index_on_device) TRYH(hipMemcpy(h->d_seg_end, seg_end.data(), sizeof(int) * seg_end.size(), hipMemcpyHostToDevice));
     if (!wdesc.empty()) {
       TRYH(hipMemcpy(h->d_wdesc, wdesc.data(), sizeof(int4) * wdesc.size(), hipMemcpyHostToDevice));
@@ -3400,7 +3594,7 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
-                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv};
+                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -3512,7 +3706,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const long long nAb = (long long)(nA + n9);
     const unsigned grid = (unsigned)std::max<long long>((h->N + 255) / 256, std::min<long long>((nAb + 1023) / 1024, 4096));
     hipLaunchKernelGGL(k_point_inv, dim3(std::max(grid, 1u)), dim3(256), 0, h->stream, h->N, c, h->d_PL, h->d_PB, h->d_flag,
-                       h->d_Ab, nAb, h->d_prog, h->slot_pace ? h->slot_nR * h->slot_nseg * PACE_STRIDE : 0);
+                       h->d_Ab, nAb, h->d_prog, h->slot_pace ? (long long)h->slot_rounds * h->slot_nR * h->slot_nseg * PACE_STRIDE : 0LL);
   }
   if (h->use_pairs) {
     Timed t(h, MVBA_K_SCHUR);
@@ -3523,7 +3717,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
         hipLaunchKernelGGL(k_schur_slots, dim3(h->n_waves), dim3(64), SLOT_LDS, h->stream, h->d_wdesc,
                            h->d_wunits, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial,
                            h->pair_static ? nullptr : h->d_q_head, h->slot_nR, h->n_waves / std::max(1, h->slot_nR), h->d_seg_end,
-                           h->slot_pace ? h->d_prog : nullptr, h->slot_nseg, h->slot_lag, h->d_trace);
+                           h->slot_pace ? h->d_prog : nullptr, h->slot_nseg, h->slot_lag, h->d_trace, h->d_range_o0);
     } else if (h->n_units) {
       const bool stat = h->pair_static;
       hipLaunchKernelGGL(big ? k_schur_pairs_big : k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
@@ -3770,7 +3964,8 @@ int mvba_get_info(mvba_handle *h, int64_t *out8) {
   out8[0] = h->n_items;
   out8[1] = h->n_items_offdiag;
   out8[2] = h->n_units;
-  out8[3] = h->schur_mode;
+  out8[3] = h->schur_mode | ((long long)(h->schur_mode == SCHUR_SLOTS ? h->slot_rounds : 0) << 8) |
+            ((long long)(h->schur_mode == SCHUR_SLOTS ? h->slot_groups : 0) << 32);
   out8[4] = h->rccl_version;
   out8[5] = NCCL_VERSION_CODE;
   out8[6] = h->nranks;

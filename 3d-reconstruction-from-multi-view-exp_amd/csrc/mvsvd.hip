@@ -459,6 +459,8 @@ __global__ __launch_bounds__(JT) void k_jacobi_small(double *__restrict__ Ag, do
   __shared__ int s_rot[2];  // "a pair is still above the threshold" after the even / odd sweeps
   const int tid = threadIdx.x;
   const int np = (n + 1) & ~1, half = np / 2;
+  // (a batch: block b solves problem b -- the dual depth iteration's 12 x 12 problems, one per image)
+  Ag += (size_t)blockIdx.x * n * n; Vg += (size_t)blockIdx.x * n * n; sweeps_done += blockIdx.x;
   for (int e = tid; e < JW * JW; e += (int)blockDim.x) {
     const int i = e / JW, j = e % JW;
     Ab[0][jblk(i, j)] = (i < n && j < n) ? Ag[(size_t)i * n + j] : 0.0;  // (the phantom row / column of an odd order: zeros)
@@ -677,6 +679,267 @@ __global__ __launch_bounds__(256) void k_scale_rows(const T *__restrict__ X, con
   }
 }
 
+
+// ---- projective-depth iteration on the device (mvsvd_depth_step; ref lib/perspective_camera_calibration.py:93-129
+// primary, :182-224 dual).  After the factorisation of the re-weighted matrix the workspace holds M = U[:, :4]
+// (dMr, [3m][4]) and S = diag(sigma) Vt[:4] (dS, [4][rows]); the depth update reads them, the resident observations
+// X ([rows][3m]) and writes the new depths z ([rows][m]) -- nothing crosses PCIe but the reprojection error.
+// The eigenproblems in their low-rank form (oracle/depth_oracle.py restates them in NumPy):
+//   primary  per point a: C[k][i] = (x_ak . u_ki) / |x_ak| (m x 4); dominant eigenvector v of the 4 x 4 companion
+//            C^T C by cyclic Jacobi in registers; xi = C v / |C v|  (= the dominant eigenvector of the reference's
+//            m x m matrix C C^T, :99-118)
+//   dual     per image k: Z[a] = V4[a] (x) x_ak / |x_ak| (rows x 12), V4 = right singular vectors; the 12 x 12
+//            companion Z^T Z = sum_a (v v^T) (x) (x^ x^^T) has 10 x 6 distinct entries, summed over the rows per block
+//            in row order and over the blocks in block order (no atomics); batched Jacobi; xi = Z w / sqrt(lambda)
+//            (= the dominant eigenvector of the reference's N x N matrix, :188-213, in O(N) memory)
+// Signs: xi of a point is flipped when its sum is negative (ref :121 / :217); in the dual form every image's vector is
+// first oriented to a non-negative sum (the reference inherits LAPACK's eigenvector sign there: projectively equivalent).
+// Reprojection error (:43-58) from the same M, S, per-thread sums in row order, fixed tree, fixed block order.
+
+// dominant eigenvector of the symmetric 4 x 4 matrix g (upper triangle, row-major 10 values): cyclic Jacobi with
+// the rotations of the small solver above (same (c, s) convention), everything in registers
+__device__ __forceinline__ void dominant_eigvec4(const double (&g)[10], double (&v)[4]) {
+  double A[4][4], V[4][4];
+  {
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = i; j < 4; ++j, ++e) A[i][j] = A[j][i] = g[e];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  const double tol2 = 1e-30;
+  for (int sweep = 0; sweep < 24; ++sweep) {
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double c, sn;
+        if (!jacobi_rotation(A[p][p], A[p][q], A[q][q], tol2, c, sn)) continue;
+        any = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // rows p, q
+          const double ap = A[p][j], aq = A[q][j];
+          A[p][j] = c * ap - sn * aq;
+          A[q][j] = sn * ap + c * aq;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // columns p, q (and the eigenvectors)
+          const double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - sn * aq;
+          A[i][q] = sn * ap + c * aq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - sn * vq;
+          V[i][q] = sn * vp + c * vq;
+        }
+        const double sym = 0.5 * (A[p][q] + A[q][p]);  // (annihilated up to rounding; keep the two copies equal)
+        A[p][q] = A[q][p] = sym;
+      }
+    if (!any) break;
+  }
+  int best = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (A[i][i] > A[best][best]) best = i;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = best == 0 ? V[i][0] : (best == 1 ? V[i][1] : (best == 2 ? V[i][2] : V[i][3]));
+}
+
+// sum of a value over the block's threads in a fixed tree -> part[blockIdx.x]
+__device__ __forceinline__ void block_sum_to(double v, double *__restrict__ part) {
+  __shared__ double s_red[256];
+  s_red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = s_red[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill(T *__restrict__ p, long long n, T v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// squared reprojection error of observation x (3) under P = U4_k (3 x 4) and the point's S column
+__device__ __forceinline__ double reproj_err2(const double *u /*[3][4]*/, const double (&s)[4], double x0, double x1, double x2) {
+  const double p0 = u[0] * s[0] + u[1] * s[1] + u[2] * s[2] + u[3] * s[3];
+  const double p1 = u[4] * s[0] + u[5] * s[1] + u[6] * s[2] + u[7] * s[3];
+  const double p2 = u[8] * s[0] + u[9] * s[1] + u[10] * s[2] + u[11] * s[3];
+  const double d0 = x0 - p0 / p2, d1 = x1 - p1 / p2, d2 = x2 - p2 / p2;
+  return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, const double *__restrict__ Mr, const T *__restrict__ S,
+                                                       long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
+  extern __shared__ double sU[];  // [3m][4]
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) sU[q] = Mr[q];
+  __syncthreads();
+  double esum = 0.0;
+  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
+    const T *xr = X + a * 3 * m;
+    T *zr = z + a * m;
+    double s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+    double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < m; ++k) {
+      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      const double *u = sU + 12 * k;
+      double c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = (x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv;
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j, ++e) g[e] = fma(c[i], c[j], g[e]);
+      esum += reproj_err2(u, s, x0, x1, x2);
+    }
+    double v[4];
+    dominant_eigvec4(g, v);
+    double nrm2 = 0.0, sum = 0.0;
+    for (int k = 0; k < m; ++k) {  // xi_k = C[k] . v (unnormalised); z <- xi_k / |x_ak| for now
+      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      const double *u = sU + 12 * k;
+      double xi = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xi = fma((x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv, v[i], xi);
+      nrm2 = fma(xi, xi, nrm2);
+      sum += xi;
+      zr[k] = (T)(xi * inv);
+    }
+    const double sc = (sum < 0.0 ? -1.0 : 1.0) / sqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
+    for (int k = 0; k < m; ++k) zr[k] = (T)((double)zr[k] * sc);
+  }
+  block_sum_to(esum, Epart);
+}
+
+// dual, pass 1: per block and image the 60 distinct entries of sum_a (v v^T) (x) (x^ x^^T) and the 12 column sums of Z.
+// Thread t < 10 m: image t / 10, pair (i <= j) of V4 components t % 10 -> 6 sums over (c <= d);
+// thread 10 m <= t < 14 m: image, component i -> 3 column sums.  Rows in order, no atomics.
+__constant__ int c_pair_i[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
+__constant__ int c_pair_j[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+template <typename T>
+__global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
+                                                   double is3, long long n_rows, int m, long long rows_per_block,
+                                                   double *__restrict__ part /*[blocks][14 m][6]*/) {
+  const long long a0 = (long long)blockIdx.x * rows_per_block, a1 = min(n_rows, a0 + rows_per_block);
+  const double isg[4] = {is0, is1, is2, is3};
+  for (int task = threadIdx.x; task < 14 * m; task += blockDim.x) {
+    const bool gram = task < 10 * m;
+    const int k = gram ? task / 10 : (task - 10 * m) / 4;
+    const int i = gram ? c_pair_i[task % 10] : (task - 10 * m) % 4, j = gram ? c_pair_j[task % 10] : i;
+    const double si = isg[i], sj = gram ? isg[j] : 1.0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (long long a = a0; a < a1; ++a) {
+      const T *xr = X + a * 3 * m + 3 * k;
+      const double x0 = (double)xr[0], x1 = (double)xr[1], x2 = (double)xr[2];
+      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
+      const double vi = (double)S[(size_t)i * n_rows + a] * si;
+      if (gram) {
+        const double pq = vi * ((double)S[(size_t)j * n_rows + a] * sj);
+        acc[0] = fma(pq, h0 * h0, acc[0]); acc[1] = fma(pq, h0 * h1, acc[1]); acc[2] = fma(pq, h0 * h2, acc[2]);
+        acc[3] = fma(pq, h1 * h1, acc[3]); acc[4] = fma(pq, h1 * h2, acc[4]); acc[5] = fma(pq, h2 * h2, acc[5]);
+      } else {
+        acc[0] = fma(vi, h0, acc[0]); acc[1] = fma(vi, h1, acc[1]); acc[2] = fma(vi, h2, acc[2]);
+      }
+    }
+    double *o = part + ((size_t)blockIdx.x * 14 * m + task) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = acc[q];
+  }
+}
+
+// dual, pass 2: block partials summed in block order -> G12[k][12][12] (symmetric, index (i, c) = 3 i + c) and colsum[k][12]
+__global__ void k_dual_reduce(const double *__restrict__ part, int blocks, int m, double *__restrict__ G12, double *__restrict__ colsum) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 14 * m * 6) return;
+  const int task = t / 6, q = t % 6;
+  double v = 0.0;
+  for (int b = 0; b < blocks; ++b) v += part[((size_t)b * 14 * m + task) * 6 + q];
+  if (task < 10 * m) {
+    const int k = task / 10, i = c_pair_i[task % 10], j = c_pair_j[task % 10];
+    const int c = q < 3 ? 0 : (q < 5 ? 1 : 2), d = q < 3 ? q : (q < 5 ? q - 2 : 2);
+    double *G = G12 + (size_t)k * 144;
+    G[(3 * i + c) * 12 + 3 * j + d] = v; G[(3 * i + d) * 12 + 3 * j + c] = v;
+    G[(3 * j + c) * 12 + 3 * i + d] = v; G[(3 * j + d) * 12 + 3 * i + c] = v;
+  } else if (q < 3) {
+    const int k = (task - 10 * m) / 4, i = (task - 10 * m) % 4;
+    colsum[(size_t)k * 12 + 3 * i + q] = v;
+  }
+}
+
+// dual, pass 3 (after the batched Jacobi: eigenvalues on the diagonal of G12[k], eigenvectors in the columns of V12[k]):
+// w_k = +- v_max / sqrt(lambda_max), oriented so that the image's depth vector Z w has a non-negative sum
+__global__ void k_dual_vec(const double *__restrict__ G12, const double *__restrict__ V12, const double *__restrict__ colsum, int m,
+                           double *__restrict__ w12, int *__restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const double *G = G12 + (size_t)k * 144, *V = V12 + (size_t)k * 144;
+  int best = 0;
+  for (int i = 1; i < 12; ++i)
+    if (G[i * 13] > G[best * 13]) best = i;
+  const double lam = G[best * 13];
+  if (!(lam > 0.0)) { atomicOr(flag, 1); return; }
+  double dot = 0.0;
+  for (int i = 0; i < 12; ++i) dot += colsum[(size_t)k * 12 + i] * V[i * 12 + best];
+  const double sc = (dot < 0.0 ? -1.0 : 1.0) / sqrt(lam);
+  for (int i = 0; i < 12; ++i) w12[(size_t)k * 12 + i] = sc * V[i * 12 + best];
+}
+
+// dual, pass 4: xi[a][k] = Z_k[a] . w_k, the row's sign rule, z = xi / |x|, reprojection error
+template <typename T>
+__global__ __launch_bounds__(256) void k_dual_apply(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
+                                                    double is3, const double *__restrict__ Mr, const double *__restrict__ w12,
+                                                    long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
+  extern __shared__ double sm[];  // U4 [3m][4], then w [m][12]
+  double *sU = sm, *sW = sm + 12 * (size_t)m;
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) { sU[q] = Mr[q]; sW[q] = w12[q]; }
+  __syncthreads();
+  double esum = 0.0;
+  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
+    const T *xr = X + a * 3 * m;
+    T *zr = z + a * m;
+    double s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+    const double v4[4] = {s[0] * is0, s[1] * is1, s[2] * is2, s[3] * is3};
+    double sum = 0.0;
+    for (int k = 0; k < m; ++k) {
+      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
+      const double *w = sW + 12 * k;
+      double xi = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xi = fma(v4[i], h0 * w[3 * i] + h1 * w[3 * i + 1] + h2 * w[3 * i + 2], xi);
+      sum += xi;
+      zr[k] = (T)(xi * inv);
+      esum += reproj_err2(sU + 12 * k, s, x0, x1, x2);
+    }
+    if (sum < 0.0)
+      for (int k = 0; k < m; ++k) zr[k] = (T)(-(double)zr[k]);  // ref :217
+  }
+  block_sum_to(esum, Epart);
+}
+
+__global__ void k_depth_error(const double *__restrict__ Epart, int blocks, double count, double f0, double *__restrict__ out) {
+  if (blockIdx.x || threadIdx.x) return;
+  double t = 0.0;
+  for (int b = 0; b < blocks; ++b) t += Epart[b];
+  out[0] = f0 * sqrt(t / count);  // ref :56
+}
+
 }  // namespace
 
 // Workspace: the resident matrix and every buffer a factorisation needs, allocated once.
@@ -684,13 +947,16 @@ struct mvsvd_handle {
   int device = 0, dtype = 0, n = 0;
   long long max_rows = 0, n_rows = 0, base_rows = 0;  // rows of the loaded matrix (dW) / of the resident base (dX)
   hipStream_t st = nullptr;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};
   void *dW = nullptr, *dS = nullptr;
   double *dG = nullptr, *dV = nullptr, *dV1 = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr, *dpart2 = nullptr, *dB = nullptr;
   int *dsw = nullptr;
   void *dX = nullptr, *dz = nullptr;  // mvsvd_load_base / mvsvd_run_scaled: resident base matrix, the depths of one call
   double *dgs = nullptr;              // column-group partial sums and scales
   bool base_loaded = false;
+  int depth_group = 0;                // mvsvd_depth_begin: columns per image (3); 0 = no depth loop started
+  double *ddep = nullptr;             // depth iteration: error partials, 12 x 12 problems, vectors (one allocation)
+  int *ddflag = nullptr;
   int chunks = 1, rank_cap = 0;
   double h2d_ms = 0.0;
   bool loaded = false;
@@ -810,7 +1076,7 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
     MVBA_HIP(hipStreamSynchronize(st));  // Mg is reused by the next group
   }
   hipEventRecord(h->ev[5], st);
-  MVBA_HIP(hipMemcpyAsync(S, h->dS, sizeof(T) * (size_t)n_rows * n_rank, hipMemcpyDeviceToHost, st));
+  if (S) MVBA_HIP(hipMemcpyAsync(S, h->dS, sizeof(T) * (size_t)n_rows * n_rank, hipMemcpyDeviceToHost, st));  // (null: S stays on the device)
   MVBA_HIP(hipStreamSynchronize(st));
   MVBA_HIP(hipGetLastError());
   if (timings) {
@@ -829,6 +1095,95 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
 }
 
 }  // namespace
+
+namespace {
+constexpr int GS_BLOCKS = 512;
+
+// dW <- the resident base re-weighted by the depths in dz and normalised (see mvsvd_run_scaled)
+int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
+  const int ng = h->n / group;
+  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
+  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
+  const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->base_rows + 255) / 256));
+  const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->base_rows / 64 + 1));
+  if (h->dtype == 0) {
+    if (norm == 2) {
+      hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+    }
+    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
+  } else {
+    if (norm == 2) {
+      hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, h->dgs);
+      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+    }
+    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
+  }
+  MVBA_HIP(hipGetLastError());
+  h->n_rows = h->base_rows;  // dW now holds the re-weighted base (a mvsvd_load in between may have changed n_rows)
+  h->loaded = true;
+  return MVBA_OK;
+}
+
+constexpr int DEPTH_BLOCKS = 2048;  // blocks of the per-point passes / of the dual Gram pass
+
+template <typename T>
+int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timings) {
+  const int n = h->n, m = n / 3;
+  const long long rows = h->base_rows;
+  int rc = scale_base_into_w(h, 3, method);
+  if (rc) return rc;
+  std::vector<T> M((size_t)n * 4), sigma(n);
+  rc = run<T>(h, 4, 0, M.data(), sigma.data(), (T *)nullptr, (T *)nullptr, timings);  // dMr = M, dS = S stay on the device
+  if (rc) return rc;
+  // ddep: [DEPTH_BLOCKS] error partials | [1] error | G12 [m][144] | V12 [m][144] | colsum [m][12] | w12 [m][12] | dual partials
+  const int dual_blocks = std::max(64, std::min(DEPTH_BLOCKS, 16384 / m));  // (their partials: 14 m x 6 doubles each)
+  const long long rpb = (rows + dual_blocks - 1) / dual_blocks;
+  const int gblocks = (int)((rows + rpb - 1) / rpb);
+  const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + (size_t)dual_blocks * 14 * m * 6;
+  if (!h->ddep) {
+    MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));
+    MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
+  }
+  double *Epart = h->ddep, *Eout = Epart + DEPTH_BLOCKS, *G12 = Eout + 8, *V12 = G12 + (size_t)m * 144, *colsum = V12 + (size_t)m * 144,
+         *w12 = colsum + (size_t)m * 12, *gpart = w12 + (size_t)m * 12;
+  const int pgrid = (int)std::max<long long>(1, std::min<long long>(DEPTH_BLOCKS, (rows + 255) / 256));
+  hipStream_t st = h->st;
+  hipEventRecord(h->ev[6], st);
+  if (method == 1) {
+    hipLaunchKernelGGL(k_depth_primary<T>, dim3(pgrid), dim3(256), sizeof(double) * 12 * m, st, (const T *)h->dX, h->dMr, (const T *)h->dS, rows, m,
+                       (T *)h->dz, Epart);
+  } else {
+    double is[4];
+    for (int i = 0; i < 4; ++i) {
+      if (!((double)sigma[i] > 0.0)) return fail(MVBA_ERR_SINGULAR, "measurement matrix has rank < 4");
+      is[i] = 1.0 / (double)sigma[i];
+    }
+    MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), 0, st, (const T *)h->dX, (const T *)h->dS, is[0], is[1], is[2], is[3], rows, m, rpb, gpart);
+    hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 255) / 256), dim3(256), 0, st, gpart, gblocks, m, G12, colsum);
+    hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
+    hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
+    hipLaunchKernelGGL(k_dual_apply<T>, dim3(pgrid), dim3(256), sizeof(double) * 24 * m, st, (const T *)h->dX, (const T *)h->dS, is[0], is[1], is[2],
+                       is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
+  }
+  hipLaunchKernelGGL(k_depth_error, dim3(1), dim3(1), 0, st, Epart, pgrid, (double)rows * (double)m, f0, Eout);
+  hipEventRecord(h->ev[7], st);
+  MVBA_HIP(hipGetLastError());
+  int fl = 0;
+  MVBA_HIP(hipMemcpyAsync(E, Eout, sizeof(double), hipMemcpyDeviceToHost, st));
+  if (method == 2) MVBA_HIP(hipMemcpyAsync(&fl, h->ddflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
+  if (fl) return fail(MVBA_ERR_SINGULAR, "depth iteration: an image's 12 x 12 companion matrix has no positive eigenvalue");
+  if (timings) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->ev[6], h->ev[7]);
+    timings[0] = ms;  // (no upload in a depth step: slot 0 carries the depth-update kernels instead)
+  }
+  return MVBA_OK;
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -870,7 +1225,7 @@ void mvsvd_destroy(mvsvd_handle *h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
   for (void *p : {h->dW, h->dS, (void *)h->dG, (void *)h->dV, (void *)h->dV1, (void *)h->dsum, (void *)h->dMr, (void *)h->dmu,
-                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs})
+                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs, (void *)h->ddep, (void *)h->ddflag})
     if (p) hipFree(p);
   for (auto &e : h->ev)
     if (e) hipEventDestroy(e);
@@ -928,36 +1283,55 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   if (ng > 256) return fail(MVBA_ERR_BADARG, "at most 256 column groups");
   MVBA_HIP(hipSetDevice(h->device));
   const size_t el = h->dtype ? 8 : 4;
-  constexpr int GS_BLOCKS = 512;
   if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
-  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
-  h->n_rows = h->base_rows;  // dW is about to hold the re-weighted base (a mvsvd_load in between may have changed it)
   hipEventRecord(h->ev[0], h->st);
   MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
   hipEventRecord(h->ev[1], h->st);
-  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
-  const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->base_rows + 255) / 256));
-  const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->base_rows / 64 + 1));
-  if (h->dtype == 0) {
-    if (norm == 2) {
-      hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, h->dgs);
-      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
-    }
-    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
-  } else {
-    if (norm == 2) {
-      hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, h->dgs);
-      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
-    }
-    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
-  }
+  h->depth_group = 0;  // (the caller's depths replace whatever a depth loop held)
+  int rc = scale_base_into_w(h, group, norm);
+  if (rc) return rc;
   MVBA_HIP(hipStreamSynchronize(h->st));
   float ms = 0.f;
   hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
   h->h2d_ms = ms;
-  h->loaded = true;
   if (h->dtype == 0) return run<float>(h, n_rank, 0, (float *)M, (float *)sigma, (float *)S, (float *)nullptr, timings_ms);
   return run<double>(h, n_rank, 0, (double *)M, (double *)sigma, (double *)S, (double *)nullptr, timings_ms);
+}
+
+int mvsvd_depth_begin(mvsvd_handle *h, int32_t group) {
+  if (!h) return fail(MVBA_ERR_BADARG, "null handle");
+  if (!h->base_loaded) return fail(MVBA_ERR_STATE, "mvsvd_depth_begin before mvsvd_load_base");
+  if (group != 3 || h->n % 3) return fail(MVBA_ERR_BADARG, "the depth iteration works on homogeneous image coordinates: group = 3, n_cols = 3 m");
+  if (h->n / 3 > 256) return fail(MVBA_ERR_BADARG, "at most 256 images");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t el = h->dtype ? 8 : 4;
+  const int ng = h->n / 3;
+  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
+  const long long cnt = h->base_rows * ng;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(4096, (cnt + 255) / 256));
+  if (h->dtype == 0) hipLaunchKernelGGL(k_fill<float>, dim3(grid), dim3(256), 0, h->st, (float *)h->dz, cnt, 1.0f);
+  else hipLaunchKernelGGL(k_fill<double>, dim3(grid), dim3(256), 0, h->st, (double *)h->dz, cnt, 1.0);
+  MVBA_HIP(hipGetLastError());
+  h->depth_group = 3;
+  return MVBA_OK;
+}
+
+int mvsvd_depth_step(mvsvd_handle *h, int32_t method, double f0, double *E, double *timings_ms) {
+  if (!h || !E) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->base_loaded || h->depth_group != 3) return fail(MVBA_ERR_STATE, "mvsvd_depth_step before mvsvd_depth_begin");
+  if (method != 1 && method != 2) return fail(MVBA_ERR_BADARG, "method must be 1 (primary) or 2 (dual)");
+  if (h->n < 12) return fail(MVBA_ERR_BADARG, "the rank-4 depth iteration needs at least 4 images");
+  MVBA_HIP(hipSetDevice(h->device));
+  return h->dtype == 0 ? depth_step<float>(h, method, f0, E, timings_ms) : depth_step<double>(h, method, f0, E, timings_ms);
+}
+
+int mvsvd_depth_read(mvsvd_handle *h, void *z) {
+  if (!h || !z) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h->base_loaded || h->depth_group != 3) return fail(MVBA_ERR_STATE, "mvsvd_depth_read before mvsvd_depth_begin");
+  MVBA_HIP(hipSetDevice(h->device));
+  MVBA_HIP(hipMemcpyAsync(z, h->dz, (h->dtype ? 8 : 4) * (size_t)h->base_rows * (h->n / 3), hipMemcpyDeviceToHost, h->st));
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  return MVBA_OK;
 }
 
 int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank, int32_t center, void *M,

@@ -74,6 +74,9 @@ SIGNATURES = {
     "mvsvd_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
     "mvsvd_load_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mvsvd_run_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
+    "mvsvd_depth_begin": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mvsvd_depth_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp, _dp]),
+    "mvsvd_depth_read": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvsvd_destroy": (None, [C.c_void_p]),
 }
 
@@ -234,8 +237,9 @@ class HipEngine:
 
     def schur_info(self):
         i = self._info()
-        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": ("strip", "pairs", "slots")[i[3]],
-                "slot_rows": i[7]}  # slot form: step-major rows incl. the padding rows of the bounded-skew merge
+        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": ("strip", "pairs", "slots")[i[3] & 0xff],
+                "slot_rows": i[7],  # slot form: step-major rows incl. the padding rows of the bounded-skew merge
+                "slot_rounds": (i[3] >> 8) & 0xffffff, "slot_groups": i[3] >> 32}
 
     def rccl_version(self):
         i = self._info()
@@ -359,6 +363,27 @@ class SvdWorkspace:
         raise_for(self.lib.mvsvd_run_scaled(self._h, z.ctypes.data, int(group), int(norm), int(n_rank), M.ctypes.data,
                                             sigma.ctypes.data, S.ctypes.data, _ptr(tm)), self.lib)
         return M, sigma, S, _tm(tm)
+
+    # -- the projective-depth loops on the device (ref perspective_camera_calibration.py:61-144, :147-235)
+    def depth_begin(self, group=3):
+        """z <- 1 on the device for the resident base (homogeneous image coordinates: group = 3)."""
+        raise_for(self.lib.mvsvd_depth_begin(self._h, int(group)), self.lib)
+
+    def depth_step(self, method, f0):
+        """One iteration (1 = primary, 2 = dual): re-weight, factorise, update the depths on the device.
+        Returns (reprojection error, timings); nothing else crosses PCIe."""
+        E = C.c_double()
+        tm = np.zeros(6)
+        raise_for(self.lib.mvsvd_depth_step(self._h, int(method), float(f0), C.byref(E), _ptr(tm)), self.lib)
+        t = _tm(tm)
+        t["depth_ms"] = t.pop("h2d_ms")  # (slot 0 of a depth step: the depth-update kernels)
+        return E.value, t
+
+    def depth_read(self):
+        """The current depths (rows of the base, n_cols / 3), float64."""
+        z = np.empty((self.base_rows, self.n_cols // 3), self.dtype)
+        raise_for(self.lib.mvsvd_depth_read(self._h, z.ctypes.data), self.lib)
+        return z.astype(np.float64, copy=False)
 
     def run(self, n_rank, center=False):
         """M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings."""

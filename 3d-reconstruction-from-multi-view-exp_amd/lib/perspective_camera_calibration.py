@@ -5,8 +5,9 @@ quadric, metric reconstruction, world-axis normalisation.
 
 Caller of the factorization SVD.  Differences from the reference:
   * every SVD of the 3m x N measurement matrix is the thin GPU one (`mvsvd_factorize`);
-  * the per-point (primary, :99-113) and per-image (dual, :188-205) eigenproblems are solved in
-    their low-rank form: the reference's m x m matrix is C C^T with C (m x 4), and its N x N
+  * the projective-depth iterations run ON THE DEVICE (`mvsvd_depth_step`: nothing but the reprojection error
+    crosses PCIe per iteration), with the per-point (primary, :99-113) and per-image (dual, :188-205)
+    eigenproblems in their low-rank form: the reference's m x m matrix is C C^T with C (m x 4), and its N x N
     matrix is the Hadamard product of a rank-4 and a rank-3 Gram matrix, i.e. Z Z^T with
     Z = row-wise Kronecker product (N x 12).  The dominant eigenvector comes from the 4 x 4
     (12 x 12) companion problem, so the dual method no longer needs O(N^2) memory;
@@ -27,56 +28,30 @@ from .factorization import factorization_method
 from .utils import unit_vec
 
 
-class _GpuSvd4:
-    """Wt (N, 3m) -> U[:, :4] (3m,4), sigma (>=4,), diag(sigma[:4]) Vt[:4] (4,N) on a device workspace
-    that lives as long as the depth loop (50-200 calls): only the matrix itself crosses PCIe."""
+class _DeviceDepthLoop:
+    """One projective-depth loop on the device (`mvsvd_depth_*`, csrc/mvsvd.hip): the homogeneous observations x
+    (N, m, 3) are uploaded ONCE, the depths z live on the device, and an iteration -- re-weight and normalise, rank-4
+    factorisation, per-point (primary) or per-image (dual) eigenproblem, depth update, reprojection error -- moves
+    8 bytes (the error) across PCIe.  The depths come back once, at the end."""
 
-    def __init__(self):
-        self._ws = None
-        self._base = None
-
-    def __call__(self, Wt: npt.NDArray):
-        from ._mvba import SvdWorkspace
-
-        Wt = np.ascontiguousarray(Wt)
-        if self._ws is None or self._ws.max_rows < Wt.shape[0] or self._ws.n_cols != Wt.shape[1] or self._ws.dtype != Wt.dtype:
-            if self._ws is not None:
-                self._ws.close()
-            self._base = None  # (the new workspace holds no base)
-            self._ws = SvdWorkspace(Wt.shape[0], Wt.shape[1], Wt.dtype if Wt.dtype in (np.float32, np.float64) else np.float64)
-        M, sigma, S, _mu, _tm = self._ws.load(Wt).run(4)
-        return M, sigma, S
-
-    def scaled(self, x: npt.NDArray, z: npt.NDArray, norm: int):
-        """The depth loops' factorisation of x o z (x (N, m, 3) homogeneous observations, z (N, m) depths), normalised
-        (norm 1: every point's 3m-vector to unit length, ref :86-87; norm 2: every image's block by its squared
-        Frobenius norm, ref :170-172): x is uploaded ONCE per loop (`mvsvd_load_base`), afterwards only z crosses
-        PCIe and the re-weighted matrix is formed on the device (`mvsvd_run_scaled`)."""
+    def __init__(self, x: npt.NDArray):
         from ._mvba import SvdWorkspace
 
         n, m = x.shape[:2]
-        if self._ws is None or self._base is not x:
-            if self._ws is not None:
-                self._ws.close()
-            self._ws = SvdWorkspace(n, 3 * m, np.float64)
-            self._ws.load_base(x.reshape(n, 3 * m))
-            self._base = x
-        M, sigma, S, _tm = self._ws.run_scaled(z, 3, norm, 4)
-        return M, sigma, S
+        self._ws = SvdWorkspace(n, 3 * m, np.float64)
+        self._ws.load_base(np.ascontiguousarray(x.reshape(n, 3 * m), dtype=np.float64))
+        self._ws.depth_begin(3)
+
+    def step(self, method: int, f0: float) -> float:
+        return self._ws.depth_step(method, f0)[0]
+
+    def depths(self) -> npt.NDArray:
+        return self._ws.depth_read()
 
     def close(self):
         if self._ws is not None:
             self._ws.close()
             self._ws = None
-            self._base = None
-
-
-def _gpu_svd4(Wt: npt.NDArray):
-    """One-shot form of ``_GpuSvd4`` (kept for callers that factorize once)."""
-    from ._mvba import svd_factorize
-
-    M, sigma, S, _mu, _tm = svd_factorize(Wt, 4)
-    return M, sigma, S
 
 
 def _create_data_matrix(x_list: list[npt.NDArray], f0: float) -> npt.NDArray:
@@ -85,89 +60,35 @@ def _create_data_matrix(x_list: list[npt.NDArray], f0: float) -> npt.NDArray:
     return x.transpose(1, 0, 2)
 
 
-def _compute_reprojection_error(x, M, S, f0) -> float:
-    """f0 * sqrt(mean |x - [M S normalised to third component 1]|^2)  (:43-58)."""
-    PX = (M @ S).reshape(-1, 3, S.shape[1]).transpose(2, 0, 1)
-    PX = PX / PX[..., 2:3]
-    return float(f0 * np.sqrt(((x - PX) ** 2).sum(axis=2).mean()))
-
-
-def _dominant_left_vector(C):
-    """Unit dominant left singular vector of each C[i] (.., p, q) with q small: the dominant
-    eigenvector of C C^T from the q x q companion C^T C."""
-    G = np.einsum("...pi,...pj->...ij", C, C)
-    lam, vec = np.linalg.eigh(G)
-    v = vec[..., -1]
-    xi = np.einsum("...pq,...q->...p", C, v)
-    return xi / np.linalg.norm(xi, axis=-1, keepdims=True)
-
-
-def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 200, svd=None):
-    """Primary method (:61-144): alternate a rank-4 fit of the column-normalised measurement
-    matrix with per-point depth updates."""
-    n_points, n_images = x.shape[:2]
-    z = np.ones((n_points, n_images))
-    x_norm = np.linalg.norm(x, axis=2)
+def _depth_iterations(x, f0, tolerance, max_iter, method, loop):
+    """The reference's loop (:77-142 / :162-233) around one device iteration: print, stop rule, final depths."""
+    loop = loop or _DeviceDepthLoop(x)
     count = 0
-    svd = svd or _GpuSvd4()
-    while True:
-        if hasattr(svd, "scaled"):  # device path: x stays resident, z is all that is uploaded
-            M, _sigma, S = svd.scaled(x, z, 1)
-        else:
-            W = x * z[..., None]
-            W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]  # every point's 3m-column to unit length
-            M, _sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
-        U4 = M.reshape(n_images, 3, 4)
-        # C[a, k, i] = (x_ak . u_ik) / |x_ak|;  A_a = C_a C_a^T is the reference's m x m matrix (:99-107)
-        C = np.einsum("akc,kci->aki", x, U4) / x_norm[..., None]
-        xi = _dominant_left_vector(C)
-        xi[xi.sum(axis=1) < 0] *= -1  # (:121)
-        z[...] = xi / x_norm
-        E = _compute_reprojection_error(x, M, S, f0)
-        count += 1
-        print(f"Iteration {count}: reprojection_error = {E:.8}")
-        if E < tolerance or count >= max_iter:
-            break
-    if count >= max_iter:
-        print("Did not converge because the maximum number of iterations was reached.")
-    return z
+    try:
+        while True:
+            E = loop.step(method, f0)
+            count += 1
+            print(f"Iteration {count}: reprojection_error = {E:.8}")
+            if E < tolerance or count >= max_iter:
+                break
+        if count >= max_iter:
+            print("Did not converge because the maximum number of iterations was reached.")
+        return loop.depths()
+    finally:
+        loop.close()
 
 
-def _compute_projective_depth_dual_method(x, f0, tolerance, max_iter: int = 50, svd=None):
-    """Dual method (:147-235): rows (images) normalised, per-image depth updates."""
-    n_points, n_images = x.shape[:2]
-    z = np.ones((n_points, n_images))
-    x_norm = np.linalg.norm(x, axis=2)          # (N, m)
-    x_hat = x / x_norm[..., None]
-    count = 0
-    svd = svd or _GpuSvd4()
-    while True:
-        if hasattr(svd, "scaled"):  # device path: x stays resident, z is all that is uploaded
-            M, sigma, S = svd.scaled(x, z, 2)
-        else:
-            W = x * z[..., None]
-            # each image's 3 x N block divided by its SQUARED Frobenius norm (:170-172)
-            W = W / (W**2).sum(axis=(0, 2))[None, :, None]
-            M, sigma, S = svd(np.ascontiguousarray(W.reshape(n_points, -1)))
-        if not (sigma[:4] > 0).all():           # rank-deficient measurement matrix: no 4th right singular vector
-            raise np.linalg.LinAlgError("measurement matrix has rank < 4")
-        V4 = (S / sigma[:4, None]).T             # (N, 4) right singular vectors
-        # B_k = (V4 V4^T) o (x_k x_k^T) / (|x||x|^T) = Z_k Z_k^T,  Z_k[a] = V4[a] (x) x_hat[a, k]
-        Z = np.einsum("ai,akc->kaic", V4, x_hat).reshape(n_images, n_points, 12)
-        xi = _dominant_left_vector(Z).T          # (N, m)
-        # eigenvector sign: B_k is entrywise non-negative near convergence (Perron vector);
-        # orient every image's vector to a non-negative sum, then the reference's row rule (:217)
-        xi *= np.where(xi.sum(axis=0) < 0, -1.0, 1.0)[None, :]
-        xi[xi.sum(axis=1) < 0] *= -1
-        z[...] = xi / x_norm
-        E = _compute_reprojection_error(x, M, S, f0)
-        count += 1
-        print(f"Iteration {count}: reprojection_error = {E:.8}")
-        if E < tolerance or count >= max_iter:
-            break
-    if count >= max_iter:
-        print("Did not converge because the maximum number of iterations was reached.")
-    return z
+def _compute_projective_depth_primary_method(x, f0, tolerance, max_iter: int = 200, loop=None):
+    """Primary method (:61-144): alternate a rank-4 fit of the column-normalised measurement matrix with per-point
+    depth updates (the dominant eigenvector of the m x m matrix of :99-107, from its 4 x 4 companion).  `loop`: an
+    object with the protocol of `_DeviceDepthLoop` (the tests inject the CPU oracle's)."""
+    return _depth_iterations(x, f0, tolerance, max_iter, 1, loop)
+
+
+def _compute_projective_depth_dual_method(x, f0, tolerance, max_iter: int = 50, loop=None):
+    """Dual method (:147-235): rows (images) normalised by their squared norm, per-image depth updates (the dominant
+    eigenvector of the N x N matrix of :188-205, from its 12 x 12 companion: O(N) memory instead of O(N^2))."""
+    return _depth_iterations(x, f0, tolerance, max_iter, 2, loop)
 
 
 # ---------------------------------------------------------------- Euclidean upgrade (:238-411)

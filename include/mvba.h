@@ -125,7 +125,8 @@ int mvba_reset_stats(mvba_handle *h);
 /* Sizes of the Schur index built at create and what the communicator runs on (bench.py prices the
  * kernels with them): out[0] (point, camera pair) items incl. diagonal pairs, out[1] off-diagonal
  * items, out[2] units (wave runs / slot lists), out[3] Schur kernel form: 0 = camera strips (round 1),
- * 1 = pair-major units (round 2), 2 = slot-resident (round 3), out[4] ncclGetVersion() of the librccl
+ * 1 = pair-major units (round 2), 2 = slot-resident (round 3) in bits 0..7, its rounds (camera-group pairs swept one
+ * after the other inside the launch) in bits 8..31 and camera groups in bits 32.., out[4] ncclGetVersion() of the librccl
  * actually loaded (0 without a communicator), out[5] the NCCL_VERSION_CODE the library was compiled
  * against, out[6] ranks, out[7] slot form: step-major item rows including the padding rows. */
 int mvba_get_info(mvba_handle *h, int64_t *out8);
@@ -223,6 +224,20 @@ int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *si
 int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows);
 int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
                      double *timings_ms);
+
+/* The depth UPDATE of those loops on the device too (ref perspective_camera_calibration.py:93-129 primary, :182-224
+ * dual): the depths z live in the workspace, and one mvsvd_depth_step is one whole iteration of the reference's loop --
+ * re-weight the resident X by z and normalise (norm = method), rank-4 factorisation, then per point (method 1, primary)
+ * the dominant eigenvector of the m x m matrix of :99-107 from its 4 x 4 companion, or per image (method 2, dual) that
+ * of the N x N matrix of :188-205 from its 12 x 12 companion (O(N) memory), the sign rules of :121 / :217,
+ * z <- xi / |x| (:124 / :220) and the reprojection error of :43-58 into *E.  Per iteration 8 bytes cross PCIe.
+ * mvsvd_depth_begin (after mvsvd_load_base; group must be 3: homogeneous image coordinates, n_cols = 3 m) sets
+ * z = 1 (:75 / :160); mvsvd_depth_read downloads the depths [n_rows][m] (the workspace's dtype), once, at the end.
+ * timings_ms (may be NULL) [6] as in mvsvd_run, except slot 0: device ms of the depth-update kernels.
+ * MVBA_ERR_SINGULAR: the re-weighted matrix has rank < 4. */
+int mvsvd_depth_begin(mvsvd_handle *h, int32_t group);
+int mvsvd_depth_step(mvsvd_handle *h, int32_t method, double f0, double *E, double *timings_ms);
+int mvsvd_depth_read(mvsvd_handle *h, void *z);
 void mvsvd_destroy(mvsvd_handle *h);
 
 #ifdef __cplusplus

@@ -68,21 +68,18 @@ def test_affine_post_svd_pipeline_against_reference(golden):
         np.testing.assert_allclose(R, d[key + "_R"], rtol=0, atol=1e-9, err_msg=key)
 
 
-def _numpy_svd4(Wt):
-    U, s, Vt = np.linalg.svd(Wt.T, full_matrices=False)
-    return U[:, :4], s, np.diag(s[:4]) @ Vt[:4]
-
-
 def test_projective_depths_low_rank_restatement_equals_reference(golden, capsys):
-    """The 4x4 / 12x12 companion-eigenproblem forms reproduce the reference's depths
-    (three forced iterations of each scheme; NumPy SVD injected so this runs without a GPU)."""
+    """The 4x4 / 12x12 companion-eigenproblem forms (oracle/depth_oracle.py: what the device kernels implement)
+    reproduce the reference's depths: three forced iterations of each scheme and the converged loops, the product's
+    loop control (print, stop rule) over the oracle's iteration -- NumPy SVD, runs without a GPU."""
     from lib import perspective_camera_calibration as P
+    from oracle.depth_oracle import HostDepthLoop
 
     d = golden("calibration")
     x = P._create_data_matrix([a.copy() for a in d["persp_x"]], 1.0)
-    z = P._compute_projective_depth_primary_method(x, 1.0, 0.0, 3, svd=_numpy_svd4)
+    z = P._compute_projective_depth_primary_method(x, 1.0, 0.0, 3, loop=HostDepthLoop(x))
     np.testing.assert_allclose(z, d["persp_primary_z3"], rtol=0, atol=1e-10)
-    z = P._compute_projective_depth_dual_method(x, 1.0, 0.0, 3, svd=_numpy_svd4)
+    z = P._compute_projective_depth_dual_method(x, 1.0, 0.0, 3, loop=HostDepthLoop(x))
     # The sign of each image's depth vector is an eigenvector sign: LAPACK-dependent in the
     # reference (one image comes out negated in this vector), always positive here; the two are
     # projectively equivalent (P_k ~ -P_k).  Compare up to that per-image sign.
@@ -94,7 +91,7 @@ def test_projective_depths_low_rank_restatement_equals_reference(golden, capsys)
     assert "Did not converge because the maximum number of iterations was reached." in out
     for m in ("primary", "dual"):
         fn = getattr(P, f"_compute_projective_depth_{m}_method")
-        z1 = fn(x, 1.0, 1e-2, svd=_numpy_svd4)
+        z1 = fn(x, 1.0, 1e-2, loop=HostDepthLoop(x))
         np.testing.assert_allclose(z1, np.abs(d[f"persp_{m}_z"]), rtol=0, atol=1e-10)
         first = capsys.readouterr().out.strip().splitlines()[0]
         assert first == str(d[f"persp_{m}_stdout"]).strip().splitlines()[0]

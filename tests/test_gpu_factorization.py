@@ -285,3 +285,55 @@ def test_depth_loop_uploads_the_depths_only_at_5m_rows():
     assert abs(float((s.astype(np.float64) ** 2).sum()) / n - 1.0) < 1e-4
     # (the upload times -- 3.0 ms of z against 8.7 ms of W -- are a measurement: tools/time_svd_scaled.py)
     assert tm["h2d_ms"] > 0 and tm_full["h2d_ms"] > 0
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_depth_iteration_on_the_device_equals_the_oracle_per_step(method):
+    """mvsvd_depth_step (one whole iteration of the reference's depth loops on the device: re-weighting, rank-4
+    factorisation, the per-point 4 x 4 / per-image 12 x 12 companion eigenproblems, sign rules, depth update,
+    reprojection error; ref perspective_camera_calibration.py:79-129, :166-224) against oracle/depth_oracle.py on a
+    3000-point x 6-image scene: error and depths after each of four iterations, 1e-9."""
+    from lib.perspective_camera_calibration import _create_data_matrix
+    from lib.synthetic import make_scene
+    from oracle.depth_oracle import HostDepthLoop
+
+    sc = make_scene(3000, 6, vis_p=1.0)
+    xd, _vis = sc.dense()
+    x = _create_data_matrix([xd[:, k, :] for k in range(6)], 1.0)
+    g = HostDepthLoop(x)
+    ws = _mvba.SvdWorkspace(3000, 18, np.float64)
+    ws.load_base(x.reshape(3000, 18))
+    ws.depth_begin(3)
+    for _ in range(4):
+        E, tm = ws.depth_step(method, 1.0)
+        Eo = g.step(method, 1.0)
+        assert E == pytest.approx(Eo, rel=1e-9, abs=1e-14)
+        np.testing.assert_allclose(ws.depth_read(), g.depths(), rtol=0, atol=1e-9)
+        assert tm["depth_ms"] > 0
+    with pytest.raises(ValueError):
+        ws.depth_step(3, 1.0)
+    # a caller's own depths (mvsvd_run_scaled) end the device loop: depth_step then asks for depth_begin again
+    ws.run_scaled(np.ones((3000, 6)), 3, 1, 4)
+    with pytest.raises(RuntimeError):
+        ws.depth_step(method, 1.0)
+    ws.close()
+
+
+def test_depth_iteration_in_float32():
+    """The same iteration on a float32 workspace: depths good to float32."""
+    from lib.perspective_camera_calibration import _create_data_matrix
+    from lib.synthetic import make_scene
+    from oracle.depth_oracle import HostDepthLoop
+
+    sc = make_scene(2000, 5, vis_p=1.0)
+    xd, _vis = sc.dense()
+    x = _create_data_matrix([xd[:, k, :] for k in range(5)], 1.0)
+    g = HostDepthLoop(x)
+    ws = _mvba.SvdWorkspace(2000, 15, np.float32)
+    ws.load_base(x.reshape(2000, 15).astype(np.float32))
+    ws.depth_begin(3)
+    for method in (1, 2):
+        E, _ = ws.depth_step(method, 1.0)
+        assert E == pytest.approx(g.step(method, 1.0), rel=1e-3)
+        np.testing.assert_allclose(ws.depth_read(), g.depths(), rtol=0, atol=2e-4)
+    ws.close()

@@ -515,13 +515,19 @@ def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_laun
 
 
 @pytest.mark.parametrize("n,m,p,form", [(3000, 14, 0.5, "strip"), (900, 300, 0.06, "strip"), (3000, 14, 0.5, "pairs"),
-                                         (3000, 14, 0.5, "slots"), (20000, 60, 0.15, "slots"), (20000, 60, 0.15, "pairs")])
+                                         (3000, 14, 0.5, "slots"), (20000, 60, 0.15, "slots"), (20000, 60, 0.15, "pairs"),
+                                         (3000, 14, 0.5, "slots:3"), (20000, 60, 0.15, "slots:4"), (2500, 300, 0.04, "slots"),
+                                         (2000, 500, 0.03, "slots")])
 def test_every_schur_kernel_form_matches_the_oracle(n, m, p, form, monkeypatch):
     """The three forms of K3 -- the camera-strip kernel (round 1, plain and column-segmented), the
-    pair-major unit kernel (round 2: what runs beyond ~100 cameras) and the slot-resident kernel
-    (round 3: the default up to ~100 cameras) -- each forced with MVBA_SCHUR, the first two in their
-    64-bit-offset build (MVBA_FORCE_BIG; the slot form has none: scenes whose records span 4 GiB run
-    the unit form), against the oracle's reduced system."""
+    pair-major unit kernel (round 2) and the slot-resident kernel (round 3: one round of all camera pairs up to
+    ~100 cameras; round 4: beyond that, one round per pair of camera GROUPS inside one launch -- "slots:g" forces
+    g groups at a small camera count, m = 300 / 500 take 4 / 7 groups by themselves) -- each forced with
+    MVBA_SCHUR, the first two in their 64-bit-offset build (MVBA_FORCE_BIG; the slot form addresses its records
+    relative to the point range instead), against the oracle's reduced system."""
+    if ":" in form:
+        form, groups = form.split(":")
+        monkeypatch.setenv("MVBA_SLOT_GROUPS", groups)
     if form != "slots":
         monkeypatch.setenv("MVBA_FORCE_BIG", "1")
     monkeypatch.setenv("MVBA_SCHUR", form)
@@ -747,7 +753,7 @@ def test_config4_in_full_on_one_gpu():
     full.close()
 
 
-@pytest.mark.parametrize("n,m,p", [(60_000, 24, 0.3), (4_000, 100, 0.1), (90, 70, 1.0)])
+@pytest.mark.parametrize("n,m,p", [(60_000, 24, 0.3), (4_000, 100, 0.1), (90, 70, 1.0), (3_000, 260, 0.05)])
 def test_schur_index_built_on_the_device_is_the_host_built_one(n, m, p, monkeypatch):
     """mvba_create builds the slot form's index with kernels (stable counting sort by pair, dealing into
     sub-lists, bounded-skew merge into step-major rows, pacing table); MVBA_INDEX=host keeps round 2's host
