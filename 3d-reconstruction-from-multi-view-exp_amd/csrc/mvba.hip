@@ -3028,8 +3028,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     // its own, the sums are per slot), so the index is built over a LOW-DISCREPANCY order: inside blocks of 8192 points
     // the next point is the best of `cand` random candidates by the summed deficit of its pairs (expected minus actual
     // count so far) -- the variance / mean of a pair's count per 2000-point window falls from 0.9 to ~0.25.  Deterministic
-    // (fixed seeds), host threads by block; skipped when too dear (candidates x items; config 4's shard: 325 pairs per
-    // point) and with MVBA_POINT_ORDER=natural.  order[i] = point at sweep position i, rank = its inverse, pkey[a] =
+    // (fixed seeds), host threads by block.  order[i] = point at sweep position i, rank = its inverse, pkey[a] =
     // observations of the points swept before a, counted from the scene's start like a record index.
     std::vector<int> order, rank;
     std::vector<long long> pkey(N, 0);
@@ -3037,8 +3036,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       const char *po = getenv("MVBA_POINT_ORDER");
       int cand = 32;
       if (const char *ev = getenv("MVBA_POINT_ORDER_CAND")) cand = std::max(1, atoi(ev));
-      bool reorder = slots && N > 0 && !(po && !strcmp(po, "natural"));
-      if (reorder && (double)T * cand > 8e9 && !(po && !strcmp(po, "greedy"))) reorder = false;
+      // MEASURED at config 3 (profiles/r04_sweep_point_order.txt): padding rows 12.4 % -> 10.4 % (8 / 32 / 64 candidates alike),
+      // k_schur_slots 1.691 -> 1.677 ms, mvba_create 0.05 -> 0.17 s: the lists' unequal LENGTHS and the pacing, not their
+      // local irregularity, are what is left -- so the natural order stays the default and MVBA_POINT_ORDER=greedy asks for this one.
+      const bool reorder = slots && N > 0 && po && !strcmp(po, "greedy");
       if (reorder) {
         order.resize(N); rank.resize(N);
         constexpr long long OB = 8192;

@@ -612,6 +612,36 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
   }
 }
 
+// ---- 64 rows per wave through LDS: the rows [base, base + rows_here) x n of a row-major matrix are one contiguous byte
+// range -- moved with coalesced accesses to / from a padded LDS tile (odd stride: a lane walking its own row is
+// conflict-free), so that a thread-per-row kernel neither reads nor writes memory at a row stride per lane
+// (k_scale_rows as one lane per row in global memory: ~4 ms of a 10 ms depth iteration at 5 M x 24 fp64).
+template <typename T>
+__device__ __forceinline__ void tile_load(const T *__restrict__ src, long long base, int rows_here, int n, T *tile, int ldt, int lane) {
+  const T *s = src + base * n;
+  int rr = lane / n, cc = lane - rr * n;
+  const int sr = 64 / n, sc = 64 - sr * n;
+  for (int q = lane; q < rows_here * n; q += 64) {
+    tile[rr * ldt + cc] = s[q];
+    cc += sc; rr += sr;
+    if (cc >= n) { cc -= n; ++rr; }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(T *__restrict__ dst, long long base, int rows_here, int n, const T *tile, int ldt, int lane) {
+  T *d = dst + base * n;
+  int rr = lane / n, cc = lane - rr * n;
+  const int sr = 64 / n, sc = 64 - sr * n;
+  for (int q = lane; q < rows_here * n; q += 64) {
+    d[q] = tile[rr * ldt + cc];
+    cc += sc; rr += sr;
+    if (cc >= n) { cc -= n; ++rr; }
+  }
+}
+constexpr size_t TILE_MAX_BYTES = 120 * 1024;  // LDS the four tiles of a block may take (plus the small operand tables: < 160 KiB)
+template <typename T>
+inline bool tile_fits(int cols) { return sizeof(T) * 4 * 64 * (size_t)(cols | 1) <= TILE_MAX_BYTES; }
+
 // ---- depth-weighted matrix from a resident base (mvsvd_run_scaled): W[a][j] = X[a][j] z[a][j / group] s,
 // s = 1 / |row a of X o z| (norm 1: every row to unit length, ref perspective_camera_calibration.py:86-87) or
 // s = 1 / sum over rows and the group's columns of (X o z)^2 (norm 2: every column group -- image -- divided by its
@@ -644,12 +674,21 @@ __global__ __launch_bounds__(256) void k_group_sumsq(const T *__restrict__ X, co
   }
 }
 
-__global__ void k_group_scale(const double *__restrict__ part, int blocks, int ng, double *__restrict__ cs) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
+// fixed-order sum of `count` values spaced `stride` apart by ONE WAVE: lane l adds the values l, l + 64, ... in order, then a
+// fixed tree over the lanes (the same result whatever the launch geometry; a single thread walking 2048 partials took 0.1-0.5 ms)
+__device__ __forceinline__ double wave_strided_sum(const double *__restrict__ p, int count, size_t stride, int lane) {
   double t = 0.0;
-  for (int b = 0; b < blocks; ++b) t += part[(size_t)b * ng + g];
-  cs[g] = 1.0 / t;
+  for (int b = lane; b < count; b += 64) t += p[(size_t)b * stride];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  return t;  // (valid in lane 0)
+}
+
+__global__ void k_group_scale(const double *__restrict__ part, int blocks, int ng, double *__restrict__ cs) {
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= ng) return;
+  const double t = wave_strided_sum(part + g, blocks, (size_t)ng, lane);
+  if (lane == 0) cs[g] = 1.0 / t;
 }
 
 template <typename T>
@@ -679,6 +718,44 @@ __global__ __launch_bounds__(256) void k_scale_rows(const T *__restrict__ X, con
   }
 }
 
+
+// the same through LDS tiles (one wave = 64 rows; columns [X row | z row] side by side in the tile)
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_rows_tiled(const T *__restrict__ X, const T *__restrict__ z, long long n_rows, int n,
+                                                          int group, int norm, const double *__restrict__ cs, T *__restrict__ W) {
+  extern __shared__ double sm_raw[];
+  const int ng = n / group, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ldt = (n + ng) | 1;
+  T *tile = reinterpret_cast<T *>(sm_raw) + (size_t)wave * 64 * ldt;
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < n_rows; base += (long long)gridDim.x * 256) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
+    tile_load(X, base, rows_here, n, tile, ldt, lane);
+    tile_load(z, base, rows_here, ng, tile + n, ldt, lane);
+    wave_sync();
+    if (lane < rows_here) {
+      T *xr = tile + lane * ldt;
+      const T *zr = xr + n;
+      double rs = 1.0;
+      if (norm == 1) {
+        double ss = 0.0;
+        for (int g = 0; g < ng; ++g) {
+          const double zz = (double)zr[g];
+          for (int c = 0; c < group; ++c) {
+            const double w = (double)xr[g * group + c] * zz;
+            ss += w * w;
+          }
+        }
+        rs = 1.0 / sqrt(ss);
+      }
+      for (int g = 0; g < ng; ++g) {
+        const double f = (double)zr[g] * (norm == 2 ? cs[g] : rs);
+        for (int c = 0; c < group; ++c) xr[g * group + c] = (T)((double)xr[g * group + c] * f);
+      }
+    }
+    wave_sync();
+    tile_store(W, base, rows_here, n, tile, ldt, lane);
+    wave_sync();
+  }
+}
 
 // ---- projective-depth iteration on the device (mvsvd_depth_step; ref lib/perspective_camera_calibration.py:93-129
 // primary, :182-224 dual).  After the factorisation of the re-weighted matrix the workspace holds M = U[:, :4]
@@ -775,98 +852,144 @@ __device__ __forceinline__ double reproj_err2(const double *u /*[3][4]*/, const 
   return d0 * d0 + d1 * d1 + d2 * d2;
 }
 
-template <typename T>
+template <typename T, bool TILED>
 __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, const double *__restrict__ Mr, const T *__restrict__ S,
                                                        long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
-  extern __shared__ double sU[];  // [3m][4]
+  extern __shared__ double sU[];  // [3m][4], then (TILED) one tile of 64 x [3m values | m depths] per wave
   for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) sU[q] = Mr[q];
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = 3 * m, ldt = (n + m) | 1;
+  T *tile = reinterpret_cast<T *>(sU + 12 * (size_t)m) + (size_t)wave * 64 * ldt;
   double esum = 0.0;
-  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
-    const T *xr = X + a * 3 * m;
-    T *zr = z + a * m;
-    double s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
-    double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < m; ++k) {
-      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-      const double *u = sU + 12 * k;
-      double c[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c[i] = (x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv;
-      int e = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j < 4; ++j, ++e) g[e] = fma(c[i], c[j], g[e]);
-      esum += reproj_err2(u, s, x0, x1, x2);
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < n_rows; base += (long long)gridDim.x * 256) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
+    if (TILED) {
+      tile_load(X, base, rows_here, n, tile, ldt, lane);
+      wave_sync();
     }
-    double v[4];
-    dominant_eigvec4(g, v);
-    double nrm2 = 0.0, sum = 0.0;
-    for (int k = 0; k < m; ++k) {  // xi_k = C[k] . v (unnormalised); z <- xi_k / |x_ak| for now
-      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-      const double *u = sU + 12 * k;
-      double xi = 0.0;
+    if (lane < rows_here) {
+      const long long a = base + lane;
+      const T *xr = TILED ? tile + lane * ldt : X + a * n;
+      T *zr = TILED ? tile + lane * ldt + n : z + a * m;
+      double s[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xi = fma((x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv, v[i], xi);
-      nrm2 = fma(xi, xi, nrm2);
-      sum += xi;
-      zr[k] = (T)(xi * inv);
+      for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+      double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < m; ++k) {
+        const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double *u = sU + 12 * k;
+        double c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = (x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = i; j < 4; ++j, ++e) g[e] = fma(c[i], c[j], g[e]);
+        esum += reproj_err2(u, s, x0, x1, x2);
+      }
+      double v[4];
+      dominant_eigvec4(g, v);
+      double nrm2 = 0.0, sum = 0.0;
+      for (int k = 0; k < m; ++k) {  // xi_k = C[k] . v (unnormalised); z <- xi_k / |x_ak| for now
+        const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double *u = sU + 12 * k;
+        double xi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi = fma((x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv, v[i], xi);
+        nrm2 = fma(xi, xi, nrm2);
+        sum += xi;
+        zr[k] = (T)(xi * inv);
+      }
+      const double sc = (sum < 0.0 ? -1.0 : 1.0) / sqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
+      for (int k = 0; k < m; ++k) zr[k] = (T)((double)zr[k] * sc);
     }
-    const double sc = (sum < 0.0 ? -1.0 : 1.0) / sqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
-    for (int k = 0; k < m; ++k) zr[k] = (T)((double)zr[k] * sc);
+    if (TILED) {
+      wave_sync();
+      tile_store(z, base, rows_here, m, tile + n, ldt, lane);
+      wave_sync();
+    }
   }
   block_sum_to(esum, Epart);
 }
 
 // dual, pass 1: per block and image the 60 distinct entries of sum_a (v v^T) (x) (x^ x^^T) and the 12 column sums of Z.
-// Thread t < 10 m: image t / 10, pair (i <= j) of V4 components t % 10 -> 6 sums over (c <= d);
-// thread 10 m <= t < 14 m: image, component i -> 3 column sums.  Rows in order, no atomics.
+// Task t < 10 m: image t / 10, pair (i <= j) of V4 components t % 10 -> 6 sums over (c <= d);
+// task 10 m <= t < 14 m: image, component i -> 3 column sums.  One thread per task, rows in order, no atomics.
 __constant__ int c_pair_i[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
 __constant__ int c_pair_j[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+constexpr int DG_ROWS = 128;  // rows staged per pass of k_dual_gram
 template <typename T>
 __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
                                                    double is3, long long n_rows, int m, long long rows_per_block,
                                                    double *__restrict__ part /*[blocks][14 m][6]*/) {
+  // staged per pass: x^ [DG_ROWS][3m] (stride 3m | 1) and v4 [DG_ROWS][4]: the normalisation happens once per (row, image),
+  // not once per task, and the tasks read LDS (rows broadcast within a wave: all its lanes are on the same row)
+  extern __shared__ double sg[];
+  const int n = 3 * m, ldx = n | 1;
+  double *sx = sg, *sv = sg + (size_t)DG_ROWS * ldx;
   const long long a0 = (long long)blockIdx.x * rows_per_block, a1 = min(n_rows, a0 + rows_per_block);
   const double isg[4] = {is0, is1, is2, is3};
-  for (int task = threadIdx.x; task < 14 * m; task += blockDim.x) {
-    const bool gram = task < 10 * m;
-    const int k = gram ? task / 10 : (task - 10 * m) / 4;
-    const int i = gram ? c_pair_i[task % 10] : (task - 10 * m) % 4, j = gram ? c_pair_j[task % 10] : i;
-    const double si = isg[i], sj = gram ? isg[j] : 1.0;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (long long a = a0; a < a1; ++a) {
-      const T *xr = X + a * 3 * m + 3 * k;
-      const double x0 = (double)xr[0], x1 = (double)xr[1], x2 = (double)xr[2];
-      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-      const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
-      const double vi = (double)S[(size_t)i * n_rows + a] * si;
-      if (gram) {
-        const double pq = vi * ((double)S[(size_t)j * n_rows + a] * sj);
-        acc[0] = fma(pq, h0 * h0, acc[0]); acc[1] = fma(pq, h0 * h1, acc[1]); acc[2] = fma(pq, h0 * h2, acc[2]);
-        acc[3] = fma(pq, h1 * h1, acc[3]); acc[4] = fma(pq, h1 * h2, acc[4]); acc[5] = fma(pq, h2 * h2, acc[5]);
-      } else {
-        acc[0] = fma(vi, h0, acc[0]); acc[1] = fma(vi, h1, acc[1]); acc[2] = fma(vi, h2, acc[2]);
+  constexpr int MAXT = 4;  // tasks per thread kept in registers (14 m <= 1024: m <= 73); beyond that the rows are re-staged per batch
+  for (int t0 = 0; t0 < 14 * m; t0 += MAXT * 256) {
+    double acc[MAXT][6];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[u][q] = 0.0;
+    for (long long r0 = a0; r0 < a1; r0 += DG_ROWS) {
+      const int nr = (int)min<long long>(DG_ROWS, a1 - r0);
+      __syncthreads();
+      for (int e = threadIdx.x; e < nr * m; e += 256) {  // (row, image): normalise
+        const int rr = e / m, k = e - rr * m;
+        const T *xr = X + (r0 + rr) * n + 3 * k;
+        const double x0 = (double)xr[0], x1 = (double)xr[1], x2 = (double)xr[2];
+        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        double *d = sx + (size_t)rr * ldx + 3 * k;
+        d[0] = x0 * inv; d[1] = x1 * inv; d[2] = x2 * inv;
+      }
+      for (int e = threadIdx.x; e < nr * 4; e += 256) sv[e] = (double)S[(size_t)(e & 3) * n_rows + r0 + (e >> 2)] * isg[e & 3];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < MAXT; ++u) {
+        const int task = t0 + u * 256 + (int)threadIdx.x;
+        if (task >= 14 * m) continue;
+        const bool gram = task < 10 * m;
+        const int k = gram ? task / 10 : (task - 10 * m) / 4;
+        const int i = gram ? c_pair_i[task % 10] : (task - 10 * m) % 4, j = gram ? c_pair_j[task % 10] : i;
+        for (int rr = 0; rr < nr; ++rr) {
+          const double *h = sx + (size_t)rr * ldx + 3 * k;
+          const double h0 = h[0], h1 = h[1], h2 = h[2], vi = sv[4 * rr + i];
+          if (gram) {
+            const double pq = vi * sv[4 * rr + j];
+            acc[u][0] = fma(pq, h0 * h0, acc[u][0]); acc[u][1] = fma(pq, h0 * h1, acc[u][1]); acc[u][2] = fma(pq, h0 * h2, acc[u][2]);
+            acc[u][3] = fma(pq, h1 * h1, acc[u][3]); acc[u][4] = fma(pq, h1 * h2, acc[u][4]); acc[u][5] = fma(pq, h2 * h2, acc[u][5]);
+          } else {
+            acc[u][0] = fma(vi, h0, acc[u][0]); acc[u][1] = fma(vi, h1, acc[u][1]); acc[u][2] = fma(vi, h2, acc[u][2]);
+          }
+        }
       }
     }
-    double *o = part + ((size_t)blockIdx.x * 14 * m + task) * 6;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) o[q] = acc[q];
+    for (int u = 0; u < MAXT; ++u) {
+      const int task = t0 + u * 256 + (int)threadIdx.x;
+      if (task >= 14 * m) continue;
+      double *o = part + ((size_t)blockIdx.x * 14 * m + task) * 6;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[q] = acc[u][q];
+    }
   }
 }
 
 // dual, pass 2: block partials summed in block order -> G12[k][12][12] (symmetric, index (i, c) = 3 i + c) and colsum[k][12]
 __global__ void k_dual_reduce(const double *__restrict__ part, int blocks, int m, double *__restrict__ G12, double *__restrict__ colsum) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per sum
   if (t >= 14 * m * 6) return;
   const int task = t / 6, q = t % 6;
-  double v = 0.0;
-  for (int b = 0; b < blocks; ++b) v += part[((size_t)b * 14 * m + task) * 6 + q];
+  const double v = wave_strided_sum(part + (size_t)task * 6 + q, blocks, (size_t)14 * m * 6, lane);
+  if (lane) return;
   if (task < 10 * m) {
     const int k = task / 10, i = c_pair_i[task % 10], j = c_pair_j[task % 10];
     const int c = q < 3 ? 0 : (q < 5 ? 1 : 2), d = q < 3 ? q : (q < 5 ? q - 2 : 2);
@@ -898,46 +1021,59 @@ __global__ void k_dual_vec(const double *__restrict__ G12, const double *__restr
 }
 
 // dual, pass 4: xi[a][k] = Z_k[a] . w_k, the row's sign rule, z = xi / |x|, reprojection error
-template <typename T>
+template <typename T, bool TILED>
 __global__ __launch_bounds__(256) void k_dual_apply(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
                                                     double is3, const double *__restrict__ Mr, const double *__restrict__ w12,
                                                     long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
-  extern __shared__ double sm[];  // U4 [3m][4], then w [m][12]
+  extern __shared__ double sm[];  // U4 [3m][4], w [m][12], then (TILED) one tile of 64 x [3m values | m depths] per wave
   double *sU = sm, *sW = sm + 12 * (size_t)m;
   for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) { sU[q] = Mr[q]; sW[q] = w12[q]; }
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = 3 * m, ldt = (n + m) | 1;
+  T *tile = reinterpret_cast<T *>(sm + 24 * (size_t)m) + (size_t)wave * 64 * ldt;
   double esum = 0.0;
-  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
-    const T *xr = X + a * 3 * m;
-    T *zr = z + a * m;
-    double s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
-    const double v4[4] = {s[0] * is0, s[1] * is1, s[2] * is2, s[3] * is3};
-    double sum = 0.0;
-    for (int k = 0; k < m; ++k) {
-      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-      const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-      const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
-      const double *w = sW + 12 * k;
-      double xi = 0.0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xi = fma(v4[i], h0 * w[3 * i] + h1 * w[3 * i + 1] + h2 * w[3 * i + 2], xi);
-      sum += xi;
-      zr[k] = (T)(xi * inv);
-      esum += reproj_err2(sU + 12 * k, s, x0, x1, x2);
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < n_rows; base += (long long)gridDim.x * 256) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
+    if (TILED) {
+      tile_load(X, base, rows_here, n, tile, ldt, lane);
+      wave_sync();
     }
-    if (sum < 0.0)
-      for (int k = 0; k < m; ++k) zr[k] = (T)(-(double)zr[k]);  // ref :217
+    if (lane < rows_here) {
+      const long long a = base + lane;
+      const T *xr = TILED ? tile + lane * ldt : X + a * n;
+      T *zr = TILED ? tile + lane * ldt + n : z + a * m;
+      double s[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+      const double v4[4] = {s[0] * is0, s[1] * is1, s[2] * is2, s[3] * is3};
+      double sum = 0.0;
+      for (int k = 0; k < m; ++k) {
+        const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
+        const double *w = sW + 12 * k;
+        double xi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi = fma(v4[i], h0 * w[3 * i] + h1 * w[3 * i + 1] + h2 * w[3 * i + 2], xi);
+        sum += xi;
+        zr[k] = (T)(xi * inv);
+        esum += reproj_err2(sU + 12 * k, s, x0, x1, x2);
+      }
+      if (sum < 0.0)
+        for (int k = 0; k < m; ++k) zr[k] = (T)(-(double)zr[k]);  // ref :217
+    }
+    if (TILED) {
+      wave_sync();
+      tile_store(z, base, rows_here, m, tile + n, ldt, lane);
+      wave_sync();
+    }
   }
   block_sum_to(esum, Epart);
 }
 
 __global__ void k_depth_error(const double *__restrict__ Epart, int blocks, double count, double f0, double *__restrict__ out) {
-  if (blockIdx.x || threadIdx.x) return;
-  double t = 0.0;
-  for (int b = 0; b < blocks; ++b) t += Epart[b];
-  out[0] = f0 * sqrt(t / count);  // ref :56
+  const double t = wave_strided_sum(Epart, blocks, 1, (int)threadIdx.x);  // one wave
+  if (threadIdx.x == 0) out[0] = f0 * sqrt(t / count);  // ref :56
 }
 
 }  // namespace
@@ -1109,15 +1245,21 @@ int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
   if (h->dtype == 0) {
     if (norm == 2) {
       hipLaunchKernelGGL(k_group_sumsq<float>, dim3(gblocks), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, h->dgs);
-      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+      hipLaunchKernelGGL(k_group_scale, dim3((ng + 3) / 4), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
     }
-    hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
+    if (tile_fits<float>(h->n + ng))
+      hipLaunchKernelGGL(k_scale_rows_tiled<float>, dim3(sgrid), dim3(256), sizeof(float) * 4 * 64 * (size_t)((h->n + ng) | 1), h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
+    else
+      hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
   } else {
     if (norm == 2) {
       hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, h->dgs);
-      hipLaunchKernelGGL(k_group_scale, dim3(1), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
+      hipLaunchKernelGGL(k_group_scale, dim3((ng + 3) / 4), dim3(256), 0, h->st, h->dgs, gblocks, ng, cs);
     }
-    hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
+    if (tile_fits<double>(h->n + ng))
+      hipLaunchKernelGGL(k_scale_rows_tiled<double>, dim3(sgrid), dim3(256), sizeof(double) * 4 * 64 * (size_t)((h->n + ng) | 1), h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
+    else
+      hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
   }
   MVBA_HIP(hipGetLastError());
   h->n_rows = h->base_rows;  // dW now holds the re-weighted base (a mvsvd_load in between may have changed n_rows)
@@ -1148,11 +1290,17 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
   double *Epart = h->ddep, *Eout = Epart + DEPTH_BLOCKS, *G12 = Eout + 8, *V12 = G12 + (size_t)m * 144, *colsum = V12 + (size_t)m * 144,
          *w12 = colsum + (size_t)m * 12, *gpart = w12 + (size_t)m * 12;
   const int pgrid = (int)std::max<long long>(1, std::min<long long>(DEPTH_BLOCKS, (rows + 255) / 256));
+  const bool tiled = tile_fits<T>(n + m) && 24 * m * sizeof(double) <= 24 * 1024;  // the rows go through LDS tiles (coalesced) while they fit
+  const size_t tile_bytes = sizeof(T) * 4 * 64 * (size_t)((n + m) | 1) + 16;
   hipStream_t st = h->st;
   hipEventRecord(h->ev[6], st);
   if (method == 1) {
-    hipLaunchKernelGGL(k_depth_primary<T>, dim3(pgrid), dim3(256), sizeof(double) * 12 * m, st, (const T *)h->dX, h->dMr, (const T *)h->dS, rows, m,
-                       (T *)h->dz, Epart);
+    if (tiled)
+      hipLaunchKernelGGL((k_depth_primary<T, true>), dim3(pgrid), dim3(256), sizeof(double) * 12 * m + tile_bytes, st, (const T *)h->dX, h->dMr,
+                         (const T *)h->dS, rows, m, (T *)h->dz, Epart);
+    else
+      hipLaunchKernelGGL((k_depth_primary<T, false>), dim3(pgrid), dim3(256), sizeof(double) * 12 * m, st, (const T *)h->dX, h->dMr,
+                         (const T *)h->dS, rows, m, (T *)h->dz, Epart);
   } else {
     double is[4];
     for (int i = 0; i < 4; ++i) {
@@ -1160,14 +1308,19 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
       is[i] = 1.0 / (double)sigma[i];
     }
     MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), 0, st, (const T *)h->dX, (const T *)h->dS, is[0], is[1], is[2], is[3], rows, m, rpb, gpart);
-    hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 255) / 256), dim3(256), 0, st, gpart, gblocks, m, G12, colsum);
+    hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), sizeof(double) * ((size_t)DG_ROWS * ((n | 1) + 4)), st, (const T *)h->dX, (const T *)h->dS,
+                       is[0], is[1], is[2], is[3], rows, m, rpb, gpart);
+    hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 3) / 4), dim3(256), 0, st, gpart, gblocks, m, G12, colsum);
     hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
     hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
-    hipLaunchKernelGGL(k_dual_apply<T>, dim3(pgrid), dim3(256), sizeof(double) * 24 * m, st, (const T *)h->dX, (const T *)h->dS, is[0], is[1], is[2],
-                       is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
+    if (tiled)
+      hipLaunchKernelGGL((k_dual_apply<T, true>), dim3(pgrid), dim3(256), sizeof(double) * 24 * m + tile_bytes, st, (const T *)h->dX, (const T *)h->dS,
+                         is[0], is[1], is[2], is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
+    else
+      hipLaunchKernelGGL((k_dual_apply<T, false>), dim3(pgrid), dim3(256), sizeof(double) * 24 * m, st, (const T *)h->dX, (const T *)h->dS,
+                         is[0], is[1], is[2], is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
   }
-  hipLaunchKernelGGL(k_depth_error, dim3(1), dim3(1), 0, st, Epart, pgrid, (double)rows * (double)m, f0, Eout);
+  hipLaunchKernelGGL(k_depth_error, dim3(1), dim3(64), 0, st, Epart, pgrid, (double)rows * (double)m, f0, Eout);
   hipEventRecord(h->ev[7], st);
   MVBA_HIP(hipGetLastError());
   int fl = 0;
@@ -1215,6 +1368,10 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+  for (const void *f : {(const void *)k_scale_rows_tiled<float>, (const void *)k_scale_rows_tiled<double>, (const void *)k_depth_primary<float, true>,
+                        (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
+                        (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>})
+    SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));  // (+ 2 KiB static in block_sum_to)
 #undef SVD_TRY
   *out = h;
   return MVBA_OK;

@@ -84,3 +84,70 @@ def numpy_allreduce(group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return allreduce
+
+
+class InProcessGroup:
+    """N ranks as N THREADS of one process sharing a GPU -- the rehearsal of an N-rank job a one-GPU box allows when
+    N processes on one card are not (this pool admits six).  Every rank owns an engine (its own stream) and runs the
+    same LM loop; `allreduce(rank)` is the callback for ``mvba_comm_init_host``: each rank deposits its array, all
+    wait, every rank sums the N deposits IN RANK ORDER into its own array (so all ranks hold bitwise the same sum,
+    as after an RCCL / gloo all-reduce), all wait again.  ctypes releases the GIL around library calls and the
+    barrier waits release it too, so the ranks' kernels overlap on the device as separate processes' would."""
+
+    def __init__(self, n_ranks: int, timeout: float = 600.0):
+        import threading
+
+        self.n = int(n_ranks)
+        self._slots = [None] * self.n
+        self._barrier = threading.Barrier(self.n, timeout=timeout)
+        self.bytes_reduced = [0] * self.n
+        self.calls = [0] * self.n
+
+    def barrier(self):
+        self._barrier.wait()
+
+    def abort(self):
+        self._barrier.abort()
+
+    def allreduce(self, rank: int):
+        def fn(a: np.ndarray):
+            self._slots[rank] = a
+            self._barrier.wait()
+            total = self._slots[0].copy()
+            for r in range(1, self.n):
+                total += self._slots[r]
+            self._barrier.wait()  # everybody has read every deposit before anybody overwrites its own
+            a[...] = total
+            self.bytes_reduced[rank] += a.nbytes
+            self.calls[rank] += 1
+
+        return fn
+
+    def attach(self, engine, rank: int):
+        engine.comm_init_host(rank, self.n, self.allreduce(rank))
+
+    def run(self, body):
+        """body(rank, group) on N threads; returns the N results in rank order.  An exception on one rank aborts the
+        barrier (the others raise BrokenBarrierError instead of waiting for ever) and is re-raised here."""
+        import threading
+
+        out, err = [None] * self.n, [None] * self.n
+
+        def wrap(r):
+            try:
+                out[r] = body(r, self)
+            except BaseException as exc:  # noqa: BLE001
+                err[r] = exc
+                self._barrier.abort()
+
+        th = [threading.Thread(target=wrap, args=(r,), name=f"rank{r}") for r in range(self.n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        first = next((e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
+        if first is None:
+            first = next((e for e in err if e is not None), None)
+        if first is not None:
+            raise first
+        return out

@@ -48,7 +48,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver o
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (f64 FMA issues 16 lanes/clk/SIMD)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_config3.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("pmc_config3.json", "pmc_config4_shard.json")]
+GATHER_CEILING_ROWS_PER_US_PER_CU = 740.0  # profiles/r03_microbench_gather_rows.txt: 717 (128-B rows) .. 759 (112-B rows) from L2, LDS-DMA
 
 
 def csrc_sha256():
@@ -70,16 +71,19 @@ def pmc_traffic(kernel, n_obs):
     (tools/final_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB; FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950).  Not measured in
     this run: the second return value names the file and the commit it was taken at."""
-    try:
-        d = json.load(open(PMC_FILE))
-        k = d["kernels"][kernel]
-        if int(d["n_obs"]) != int(n_obs):
-            return None, None
-        if d.get("csrc_sha256") != csrc_sha256():  # the kernels have changed since the counters were collected
-            return None, f"profiles/pmc_config3.json @ {d.get('commit', '?')} is STALE (kernel sources changed since): traffic omitted"
-        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, f"profiles/pmc_config3.json @ {d.get('commit', '?')}"
-    except Exception:  # noqa: BLE001
-        return None, None
+    for path in PMC_FILES:
+        try:
+            d = json.load(open(path))
+            k = d["kernels"][kernel]
+            if int(d["n_obs"]) != int(n_obs):
+                continue
+            name = "profiles/" + os.path.basename(path)
+            if d.get("csrc_sha256") != csrc_sha256():  # the kernels have changed since the counters were collected
+                return None, f"{name} @ {d.get('commit', '?')} is STALE (kernel sources changed since): traffic omitted"
+            return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0, f"{name} @ {d.get('commit', '?')}"
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
 def cpu_info():
@@ -263,6 +267,9 @@ def main():
     ap.add_argument("--config4", action="store_true",
                     help="N=1: run config 4 (10M points x 500 cameras x 5 %%, 250M observations) on the one GPU -- the N=1 point of "
                          "the config-4 scaling curve; needs ~80 GB of HBM and a few minutes of index building")
+    ap.add_argument("--config4-shard", action="store_true",
+                    help="N=1: the per-GPU shard of config 4 when it is split over 8 GPUs (1.25M points x 500 cameras x 5 %%, 31M "
+                         "observations, D = 4493) on the one GPU: per-kernel ms per solve and the roofline of its dominant kernel")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -313,8 +320,11 @@ def main():
     from lib.synthetic import make_scene, scene_shard
 
     config4 = (world > 1 and not args.weak) or args.config4
-    n_cams = args.cams or (500 if config4 else 100)
-    vis = args.vis or (0.05 if config4 else 0.1)
+    shard4 = args.config4_shard and world == 1 and not args.config4
+    n_cams = args.cams or (500 if config4 or shard4 else 100)
+    vis = args.vis or (0.05 if config4 or shard4 else 0.1)
+    if shard4 and not args.points:
+        args.points = 1_250_000
     if config4:
         n_total = args.points or 10_000_000
         lo, hi = scene_shard(n_total, n_cams, vis, rank, world)  # observation-balanced contiguous point ranges
@@ -323,6 +333,10 @@ def main():
         per = args.points or 1_000_000
         n_total, lo, hi = per * world, rank * per, (rank + 1) * per
         scaling, cfg_name = "weak", "BASELINE config 3" + (" shard per GPU" if world > 1 else "")
+        if shard4:
+            cfg_name = "BASELINE config 4, ONE of its 8 point shards on one GPU (no exchange)"
+        elif world == 1 and (args.points or args.cams or args.vis):
+            cfg_name = "custom scene (not a BASELINE config)"
     t_gen = time.perf_counter()
     sc = make_scene(n_total, n_cams, vis_p=vis, point_range=(lo, hi))
     t_gen = time.perf_counter() - t_gen
@@ -448,12 +462,34 @@ def main():
         k3_traffic, k3_src = pmc_traffic(k3_name, sc.n_obs)
         gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
         flops = info["items"] * 3 * 96 * 2
-        roof_k3 = {"kernel": k3_name + " (K3)", "bound": "hbm", "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # what bounds K3.  Slot form: the rate at which a CU gathers rows out of its L2 into LDS -- every step
+        # row is three row gathers (k-side record; l-side record or, on a diagonal row, the residual slot; point row), padding
+        # rows included -- against the ceiling of the bare gather loop (tools/microbench/gather_lines.hip).  Unit form:
+        # the fabric (L2 misses at the HBM rate).
+        n_cu = 256
+        try:
+            n_cu = int(torch.cuda.get_device_properties(device).multi_processor_count)
+        except Exception:  # noqa: BLE001
+            pass
+        gather_rows = 3 * (info["slot_rows"] or info["items"])
+        rows_rate = gather_rows / (k3_ms * 1e3) / n_cu
+        slot_form = info["kernel"] == "slots"
+        roof_k3 = {"kernel": k3_name + " (K3)",
+                   "bound": "l2_gather" if slot_form else "hbm",
+                   "bound_note": ("not HBM: the CU's L2 -> LDS row-gather pipe (see `gather`); `achieved` / `frac` price SURVEY 8d's algorithmic "
+                                  "192 B/observation against the HBM peak as the contract asks" if slot_form else
+                                  "fabric: the kernel's L2 misses run at the HBM rate (see `traffic`)"),
+                   "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,
                    "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
                    "algorithmic_bytes_per_launch": k3_bytes, "algorithmic_bytes_per_obs": 192, "avg_launch_ms": k3_ms,
                    "items": info["items"], "units": info["units"],
                    "slot_rows_incl_padding": info["slot_rows"] or None,
+                   "gather": {"row_gathers_per_launch": gather_rows, "rows_per_us_per_cu": rows_rate,
+                              "ceiling_rows_per_us_per_cu": GATHER_CEILING_ROWS_PER_US_PER_CU,
+                              "frac": rows_rate / GATHER_CEILING_ROWS_PER_US_PER_CU, "compute_units": n_cu,
+                              "definition": "3 row gathers per step row (padding rows included) / launch time / CUs; ceiling: "
+                                            "profiles/r03_microbench_gather_rows.txt (717-759 rows/us per CU from L2)"},
                    "gathered_bytes_per_launch": gather, "gather_GBs": gather / (k3_ms * 1e-3) / 1e9,
                    "fp64_tflops": flops / (k3_ms * 1e-3) / 1e12,
                    "frac_of_fp64_valu_peak": flops / (k3_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
@@ -461,7 +497,11 @@ def main():
                    "frac": k1_ach / HBM_PEAK_GBS, "traffic": k1_traffic, "traffic_source": k1_src,
                    "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
                    "algorithmic_bytes_per_launch": k1_bytes, "algorithmic_bytes_per_obs": 152, "avg_launch_ms": k1_ms}
-        step_bytes = 824 * sc.n_obs  # K1 232 + K2 208 + K3 192 + K5 192 B/obs per inner solve
+        # One inner solve, algorithmic HBM bytes.  THIS build's kernels: K1 152 B/obs + 96 B/point (one 128-B record,
+        # K2 fused), K3a 152 B/point, K3 192 B/obs, K5 4 B/obs + 176 B/point, K6 24 B/obs + 24 B/point.  SURVEY 8d's 824 B/obs
+        # (K1 232 + K2 208 + K3 192 + K5 192: the materialised 2x9 Jacobian form, which this build never writes) kept beside it.
+        own_bytes = (152 + 192 + 4 + 24) * sc.n_obs + (96 + 152 + 176 + 24) * sc.n_points
+        step_bytes = 824 * sc.n_obs
         rmse = float(np.sqrt(E_ / n_obs_total))
         out = {
             "metric": "BA iterations/sec + residual-Jacobian GObs/s, 1M pts x 100 cams fp64",
@@ -501,13 +541,22 @@ def main():
             "roofline": roof_k3 if k3_ms >= k1_ms else roof_k1,
             "roofline_resid_jac": roof_k1,
             "roofline_schur": roof_k3,
-            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_solve": step_bytes, "bytes_per_obs": 824,
-                              "achieved": step_bytes / (ms_solve * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": step_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_solve": own_bytes,
+                              "bytes_definition": "this build's kernels: 372 B/observation + 448 B/point (K1 152+96/pt, K3a 152/pt, K3 192, K5 4+176/pt, K6 24+24/pt)",
+                              "achieved": own_bytes / (ms_solve * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": own_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "survey_8d_notional": {"bytes_per_obs": 824, "algorithmic_bytes_per_solve": step_bytes,
+                                                     "achieved": step_bytes / (ms_solve * 1e-3) / 1e9,
+                                                     "frac": step_bytes / (ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     "note": "SURVEY 8d's minimum-traffic figure for a build that materialises the 2x9 Jacobian "
+                                                             "(K1 232 + K2 208 + K3 192 + K5 192 B/obs); this build moves fewer bytes, so this "
+                                                             "fraction overstates its HBM use"}},
             "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                         "argmax": int(step_ms.argmax())},
             "kernel_ms_per_step": {k: (st[k]["ms"] / args.steps if k in ("resid_jac", "schur") else v["ms"] / TABLE_STEPS)
                                    for k, v in st_table.items() if k != "counts"},
+            "kernel_ms_per_solve": {k: (st[k]["ms"] / max(n_solves, 1) if k in ("resid_jac", "schur") else v["ms"] / max(table_solves, 1))
+                                    for k, v in st_table.items() if k != "counts"},
             "kernel_ms_per_step_source": f"resid_jac and schur: hipEvents inside the timed region; the other phases: a separate pass of "
                                          f"{TABLE_STEPS} steps right after it with every phase timed (timing all of them costs ~3 % of a step)",
         }
