@@ -4,12 +4,12 @@
 The slot-resident Schur kernel keeps two gathers in flight with COUNTED `s_waitcnt vmcnt(N)`: every vector-memory
 operation of its loops is inline assembly the compiler knows nothing about, and N is their number per iteration.
 Correctness therefore rests on properties of the generated code that no C++ rule guarantees:
-  1. between the two counted waits of a loop (unrolled by two) there are exactly N vector-memory operations and no
-     scratch / buffer access (a spill inside the loop would be an uncounted operation: the 64-bit-offset build did
-     exactly that and its results were wrong);
-  2. the index registers an asm load fills are pinned (v152..v167): only those loads (and the zeros that initialise
-     them) write one, and no move reads one (a copy made between a load and its counted wait reads the register before
-     the data has landed: seen once, the gather went to a stale address);
+  1. the blocks of a loop (its own, wherever the compiler placed them) hold exactly N vector-memory operations -- the
+     LDS-DMA gathers and the index row -- and no scratch / buffer access (a spill inside the loop would be an uncounted
+     operation: the 64-bit-offset build of round 3 did exactly that and its results were wrong);
+  2. no vector-memory operation in the loops returns data to a REGISTER (round 3's index loads did, into registers that
+     had to be pinned: a value an asm load "returns" is not in its register yet, and a copy made before its counted
+     wait once sent a gather to a stale address; since round 4 the indices travel through LDS like the records);
   3. M0 (the LDS-DMA destination base) is written by the gathers' own `s_mov_b32 m0, ...` only;
   4. the kernel fits three waves per SIMD (<= 168 VGPRs); registers it spills are touched outside the loops only
      (that is property 1).
@@ -17,9 +17,8 @@ Usage: check_isa.py mvba.s   (exit status 0 = all properties hold)."""
 import re
 import sys
 
-PINNED = r"v1(?:5[2-9]|6[0-7])\b"
-COUNTS = (("vmcnt(12)", 12), ("vmcnt(14)", 14))  # diagonal / off-diagonal loop: operations per iteration
-VM_LOOP_OPS = ("global_load_lds_dwordx4", "global_load_dword ")
+COUNTS = (("vmcnt(7)", 7), ("vmcnt(8)", 8))  # diagonal / off-diagonal loop: operations per iteration (gathers + the index row)
+VM_LOOP_OPS = ("global_load_lds_dwordx4",)
 
 
 def kernel_lines(text, name="k_schur_slots"):
@@ -29,6 +28,34 @@ def kernel_lines(text, name="k_schur_slots"):
     return [ln.strip() for ln in m.group(1).splitlines()]
 
 
+def loop_blocks(lines, wait_index):
+    """Instructions of the Depth-1 blocks of the loop whose header holds the counted wait at `wait_index` (the compiler
+    annotates every block label: `.LBBx_y: ; =>This Loop Header: Depth=1` / `;   in Loop: Header=BBx_y Depth=1`; blocks it
+    moved out of line carry the annotation too), and those of its inner loops (the pacing block's poll loops)."""
+    head = max(i for i in range(wait_index + 1) if re.match(r"\.LBB\w+:.*This Loop Header: Depth=1", lines[i]))
+    name = re.match(r"\.(LBB\w+):", lines[head]).group(1)[1:]  # "BB5_35"
+    own, inner = [], []
+    cur = own
+    for i in range(head, len(lines)):
+        ln = lines[i]
+        m = re.match(r"\.LBB\w+:(.*)", ln)
+        if m:
+            note = m.group(1)
+            if i == head or f"in Loop: Header={name} Depth=1" in note:
+                cur = own
+            elif "Depth=2" in note or "Depth=3" in note or "Parent Loop" in note:
+                # an inner loop of OURS only if we are still inside this loop's label range (the next Depth-1 header ends it)
+                cur = inner
+            elif "This Loop Header: Depth=1" in note:
+                break  # the next loop of the kernel
+            else:
+                cur = None  # a block outside any loop (epilogue code placed in between)
+            continue
+        if cur is not None:
+            cur.append(ln)
+    return own, inner
+
+
 def check(text):
     errs = []
     lines = kernel_lines(text)
@@ -36,34 +63,25 @@ def check(text):
         return ["k_schur_slots not found in the ISA"]
     for count, n_ops in COUNTS:
         idx = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt " + count)]
-        if len(idx) != 2:  # the loop is unrolled by two
-            errs.append(f"expected two `s_waitcnt {count}` (loop unrolled by two), found {len(idx)}")
+        if len(idx) != 1:
+            errs.append(f"expected one `s_waitcnt {count}` (the loop's counted wait), found {len(idx)}")
             continue
-        body = lines[idx[0]:idx[1]]
-        bad = [ln for ln in body if ln.startswith(("scratch_", "buffer_"))]
+        body, inner = loop_blocks(lines, idx[0])
+        bad = [ln for ln in body + inner if ln.startswith(("scratch_", "buffer_"))]
         if bad:
-            errs.append(f"{count} loop: scratch / buffer access between the counted waits: {bad[:3]}")
-        # one iteration = the gathers + the index loads, nothing else on the straight path (the pacing block's poll and
-        # arrival sit behind a branch that is not taken between segment boundaries: sc1 loads / atomics)
-        straight = [ln for ln in body if ln.startswith(VM_LOOP_OPS) and "sc1" not in ln]
+            errs.append(f"{count} loop: scratch / buffer access inside the loop: {bad[:3]}")
+        # one iteration = the gathers + the index row, nothing else on the loop's own blocks (the pacing block's poll and
+        # arrival are the inner loops: sc1 loads and atomics behind their own vmcnt(0))
+        straight = [ln for ln in body if ln.startswith(VM_LOOP_OPS)]
         if len(straight) != n_ops:
-            errs.append(f"{count} loop: {len(straight)} vector-memory operations per iteration, the wait counts {n_ops}")
-        other = [ln for ln in body if ln.startswith(("global_load", "global_store", "flat_")) and not ln.startswith(VM_LOOP_OPS)
-                 and "sc1" not in ln]
+            errs.append(f"{count} loop: {len(straight)} LDS-DMA operations per iteration, the wait counts {n_ops}")
+        other = [ln for ln in body if ln.startswith(("global_load", "global_store", "global_atomic", "flat_")) and not ln.startswith(VM_LOOP_OPS)]
         if other:
-            errs.append(f"{count} loop: uncounted vector-memory operations: {other[:3]}")
-        start = max([i for i in range(idx[0]) if lines[i].startswith(("global_store", "global_atomic", "s_endpgm"))] or [0])
-        region = lines[start:idx[1]]  # prologue + loop (from the end of whatever wrote results before)
-        idx_loads = [ln for ln in region if ln.startswith("global_load_dword ") and "sc1" not in ln]
-        stray = [ln for ln in idx_loads if not re.match(r"global_load_dword " + PINNED, ln)]
-        if len(idx_loads) < 24 or stray:
-            errs.append(f"{count} form: index loads outside the pinned registers v152..v167: {stray[:3]} ({len(idx_loads)} loads)")
+            errs.append(f"{count} loop: vector-memory operations the wait does not count (or that return data to a register): {other[:3]}")
+        stray = [ln for ln in inner if ln.startswith(VM_LOOP_OPS)]
+        if stray:
+            errs.append(f"{count} loop: LDS-DMA inside the pacing block: {stray[:3]}")
     for ln in lines:
-        w = re.match(r"(\w+)\s+(?:v\[)?" + PINNED, ln)
-        if w and not ln.startswith("global_load_dword ") and not re.match(r"v_mov_b32_e32 " + PINNED + r", 0$", ln):
-            errs.append(f"a pinned index register is written by something other than its load: {ln}")
-        if ln.startswith("v_mov_b32") and re.search(r", " + PINNED, ln):
-            errs.append(f"a move reads a pinned index register: {ln}")
         if re.match(r"\w+\s+m0\b", ln) and not ln.startswith("s_mov_b32 m0,"):
             errs.append(f"M0 written outside the gathers' asm statements: {ln}")
     vg = re.search(r"^\s*\.set _ZN\d+_GLOBAL__N_113k_schur_slotsE\w*\.num_vgpr, (\d+)", text, re.M)
@@ -78,4 +96,4 @@ if __name__ == "__main__":
         print("check_isa: " + e, file=sys.stderr)
     if errs:
         sys.exit(1)
-    print("check_isa: k_schur_slots ok (counted waits, pinned index registers, M0, no scratch access in the loops)")
+    print("check_isa: k_schur_slots ok (counted waits, LDS-DMA only in the loops, M0, no scratch access in the loops)")

@@ -548,7 +548,9 @@ constexpr int PROW = 7 * 16;                    // staged bytes per record (slot
 constexpr int PWAVE_LDS = PSTEP * (2 * PROW + 5 * 16);  // k rows, l rows, point rows
 constexpr int UNIT_STRIDE = 104;                // doubles per unit partial
 constexpr int SLOT_BUF = PSTEP * (2 * PROW + 3 * 16);  // slot form: one packed staging buffer (k rows, l rows, 48-byte point rows)
-constexpr int SLOT_LDS = 3 * SLOT_BUF;          // ... three of them per wave: 17,136 B, nine waves per CU
+constexpr int SLOT_IDX = 64;                    // slot form: ints per step in the index (k[21] | l[21] | a[21] | pad): ONE 256-byte DMA row
+constexpr int SLOT_IDX_RING = 3;                // ... staged three steps deep in LDS
+constexpr int SLOT_LDS = 3 * SLOT_BUF + SLOT_IDX_RING * SLOT_IDX * 4;  // three staging buffers + the index ring per wave: 17,904 B, nine waves per CU
 
 __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_uniform) {
   __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
@@ -782,119 +784,89 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     // Three buffers, the gathers of TWO steps in flight: a wave of this form is one serial chain of ~1400 steps
     // for the whole launch and 9 of them share a CU, so what bounds it is steps-in-flight x latency, not
     // throughput (per-wave stamps: 1.18 us per step with one step in flight, every wave alike).
-    // Order of the vector-memory operations: iteration s issues the gather of step s + 2 and then loads the
-    // indices of step s + 4 into the register set that gather has just freed; vmcnt retires in issue order, so
-    // "all but the last iteration's operations" (`SLOT_OPS` of them: every gather and index load is
-    // unconditional, steps past the end are clamped to the last one) = step s has landed and the indices of
-    // step s + 2 are in their registers, while step s + 1 and the indices of s + 3 stay in flight.
-    // hipcc cannot be left to count these waits: it drains the queue (vmcnt(0)) before the first use of an index
-    // register that an ordinary load fills, and before LDS reads that might alias a gather in flight.  So in this
-    // loop every vector-memory operation is inline assembly the compiler knows nothing about, and the counted
-    // waits below are the only ones; each wait names the index registers it releases as in/out operands, so that
-    // no use of them can be scheduled above it.
-    constexpr int SLOT_OPS = DIAG ? 12 : 14;
-    const int last0 = n - PSTEP;  // first item of the last step
+    // The step's INDEX -- 21 k-side, 21 l-side record indices and 21 points, one 256-byte row of the step-major index --
+    // travels through LDS too: ONE LDS-DMA instruction per step (round 3 used seven 4-byte loads per step into two
+    // register sets PINNED to v152..v167, because a value an asm load "returns" is not in its register yet and the
+    // allocator once copied one out above its wait; that whole construction is gone: the indices are read from LDS
+    // by ordinary ds_read into ordinary registers, after the counted wait that covers their DMA).
+    // Order of the vector-memory operations: iteration s issues the gathers of step s + 2, then the index DMA of
+    // step s + 4 (into the ring slot whose indices, those of step s + 1, were read an iteration ago); vmcnt retires
+    // in issue order, so "all but the last iteration's operations" (`SLOT_OPS` of them: every gather and DMA is
+    // unconditional, steps past the end are clamped to the last one) = step s has landed and the indices of step
+    // s + 2 are in LDS, while step s + 1 and the indices of s + 3 stay in flight.
+    // hipcc cannot be left to count these waits (it drains the queue -- vmcnt(0) -- before LDS reads that might alias
+    // a DMA in flight), so every vector-memory operation of this loop is inline assembly the compiler knows nothing
+    // about and the counted waits below are the only ones (csrc/check_isa.py checks that on the generated code).
+    constexpr int SLOT_OPS = DIAG ? 7 : 8;
+    const int nst = n / PSTEP, last_st = nst - 1;           // steps of this wave (n is a multiple of PSTEP here)
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)wbuf;
-    const unsigned rowk0 = (unsigned)min(drow, PSTEP - 1) << 2, rowk1 = (unsigned)min(9 + drow, PSTEP - 1) << 2,
-                   rowk2 = (unsigned)min(18 + drow, PSTEP - 1) << 2;  // byte offsets of this lane's index rows
-    const unsigned rowa0 = (unsigned)min(prow, PSTEP - 1) << 2, rowa1 = (unsigned)min(prow2, PSTEP - 1) << 2;
-    const unsigned rowl = (unsigned)min(lane, PSTEP - 1) << 2;
-    // The index registers are PINNED (v152..v167, the top of the 168 a wave has at three waves per SIMD): a value an
-    // asm load "returns" is not there yet, and left to itself the register allocator may copy such a value to
-    // another register between the load and its wait (it did: a v_mov above the counted wait read the register
-    // before the load had landed, and the gather went to an address made of the old contents).  With the variable
-    // bound to one physical register every asm statement finds it in place and nothing is ever copied.
-    register int rk00 asm("v152"), rk01 asm("v153"), rk02 asm("v154"), rl00 asm("v155"), rl01 asm("v156"), rl02 asm("v157"),
-        ra00 asm("v158"), ra01 asm("v159");
-    register int rk10 asm("v160"), rk11 asm("v161"), rk12 asm("v162"), rl10 asm("v163"), rl11 asm("v164"), rl12 asm("v165"),
-        ra10 asm("v166"), ra11 asm("v167");
-    // (clang binds such a variable to its register only where it is NAMED as an asm operand, not through a
-    // reference: hence macros, not lambdas, for the statements that name them)
-#define MVBA_SET0 rk00, rk01, rk02, rl00, rl01, rl02, ra00, ra01
-#define MVBA_SET1 rk10, rk11, rk12, rl10, rl11, rl12, ra10, ra11
-#define MVBA_GLD(dst, off, base) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
-#define MVBA_LOAD_IDX_(s0, K0, K1, K2, L0, L1, L2, A0, A1)                                                              \
-  do {                                                                                                                  \
-    const int *pk = it_k + (beg + (s0)), *pl = it_l + (beg + (s0)), *pa = it_a + (beg + (s0)); /* wave-uniform */       \
-    MVBA_GLD(K0, rowk0, pk); MVBA_GLD(K1, rowk1, pk); MVBA_GLD(K2, rowk2, pk);                                          \
-    if (!DIAG) { MVBA_GLD(L0, rowk0, pl); MVBA_GLD(L1, rowk1, pl); MVBA_GLD(L2, rowk2, pl); }                           \
-    else MVBA_GLD(L0, rowl, pk);                                                                                        \
-    MVBA_GLD(A0, rowa0, pa);                                                                                            \
-    if (DIAG) MVBA_GLD(A1, rowa1, pa);                                                                                  \
-  } while (0)
-#define MVBA_LOAD_IDX(s0, ...) MVBA_LOAD_IDX_(s0, __VA_ARGS__)
-#define MVBA_WAIT_(str, K0, K1, K2, L0, L1, L2, A0, A1)                                                                 \
-  asm volatile(str : "+v"(K0), "+v"(K1), "+v"(K2), "+v"(L0), "+v"(L1), "+v"(L2), "+v"(A0), "+v"(A1)::"memory")
-#define MVBA_WAIT(str, ...) MVBA_WAIT_(str, __VA_ARGS__)
-#define MVBA_WAIT_STEP(...)                                                                                             \
-  do {                                                                                                                  \
-    if (DIAG) MVBA_WAIT("s_waitcnt vmcnt(12)", __VA_ARGS__);                                                            \
-    else MVBA_WAIT("s_waitcnt vmcnt(14)", __VA_ARGS__);                                                                 \
-  } while (0)
+    const unsigned ldsx0 = lds0 + 3 * SLOT_BUF;             // the index ring
+    const int *xring = reinterpret_cast<const int *>(wbuf + 3 * SLOT_BUF);
+    const int *xbase = it_k + beg * SLOT_IDX;               // (`beg` = first STEP of this wave; wave-uniform)
     // (32-bit byte offsets only: with 64-bit per-lane addresses this loop needs more than the 168 registers of
     // three waves per SIMD, and a spill's scratch access would be a vector-memory operation the counted waits do
-    // not know about -- scenes whose records span 4 GiB run the unit form, mvba_create sees to that)
+    // not know about -- the records are addressed from their range's first one, mvba_create sees to that)
     static_assert(!SLOTS || !BIG, "the slot form has no 64-bit-offset build");
     auto dma = [&](int row, unsigned slot16, const void *base, unsigned lds) {  // 16 bytes per lane: base[row * 128 + slot16] -> LDS
       const unsigned o = ((unsigned)row << 7) + slot16;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");
     };
+    const unsigned lane16 = (unsigned)min(lane, 15) << 4;
+    auto dma_idx = [&](int st) {  // the 256-byte index row of step st -> ring slot st % 3 (lanes 0..15, 16 bytes each)
+      const int *src = xbase + (size_t)min(st, last_st) * SLOT_IDX;  // wave-uniform
+      const unsigned dst = ldsx0 + (unsigned)(st % SLOT_IDX_RING) * (SLOT_IDX * 4);
+      if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(dst) : "memory");
+    };
     const unsigned ds16 = (unsigned)dslot << 4, ps16 = (unsigned)pslot << 4, ps16b = (unsigned)pslot2 << 4;
-    auto issue_asm = [&](unsigned buf, int k0, int k1, int k2, int l0, int l1, int l2, int a0, int a1) {
+    const int xr0 = min(drow, PSTEP - 1), xr1 = min(9 + drow, PSTEP - 1), xr2 = min(18 + drow, PSTEP - 1);  // this lane's rows of a step
+    const int xa0 = 2 * PSTEP + min(prow, PSTEP - 1), xa1 = 2 * PSTEP + min(prow2, PSTEP - 1), xl = min(lane, PSTEP - 1);
+    auto issue_step = [&](int st) {  // gathers of step st from its indices in the ring (landed: the caller's wait saw to it)
+      const int *x = xring + (st % SLOT_IDX_RING) * SLOT_IDX;
+      const unsigned buf = lds0 + (unsigned)(st % 3) * BUFSZ;
       const unsigned kb = buf, lb = buf + LB_OFF, pb_ = buf + PB_OFF;
-      if (lane < 63) {
-        dma(k0, ds16, rec, kb);
-        if (!DIAG) dma(l0, ds16, rec, lb);
-        dma(k1, ds16, rec, kb + 9 * PROW);
-        if (!DIAG) dma(l1, ds16, rec, lb + 9 * PROW);
-        if (!DIAG) dma(a0, ps16, PB, pb_);
-      }
-      if (lane < 7 * (PSTEP - 18)) {
-        dma(k2, ds16, rec, kb + 18 * PROW);
-        if (!DIAG) dma(l2, ds16, rec, lb + 18 * PROW);
-      }
-      if (DIAG) {
-        if (lane < PSTEP) dma(l0, 7u << 4, rec, lb);
+      const int k0 = x[xr0], k1 = x[xr1], k2 = x[xr2];
+      if (!DIAG) {
+        const int l0 = x[PSTEP + xr0], l1 = x[PSTEP + xr1], l2 = x[PSTEP + xr2], a0 = x[xa0];
+        if (lane < 63) {
+          dma(k0, ds16, rec, kb);
+          dma(l0, ds16, rec, lb);
+          dma(k1, ds16, rec, kb + 9 * PROW);
+          dma(l1, ds16, rec, lb + 9 * PROW);
+          dma(a0, ps16, PB, pb_);
+        }
+        if (lane < 7 * (PSTEP - 18)) {
+          dma(k2, ds16, rec, kb + 18 * PROW);
+          dma(l2, ds16, rec, lb + 18 * PROW);
+        }
+      } else {
+        const int kl = x[xl], a0 = x[xa0], a1 = x[xa1];
+        if (lane < 63) {
+          dma(k0, ds16, rec, kb);
+          dma(k1, ds16, rec, kb + 9 * PROW);
+        }
+        if (lane < 7 * (PSTEP - 18)) dma(k2, ds16, rec, kb + 18 * PROW);
+        if (lane < PSTEP) dma(kl, 7u << 4, rec, lb);  // l-side == k-side: only the residual (slot 7) is fetched
         dma(a0, ps16, PB, pb_);
         if (lane < 5 * PSTEP - 64) dma(a1, ps16b, PB, pb_ + 1024);
       }
     };
-    rk00 = rk01 = rk02 = rl00 = rl01 = rl02 = ra00 = ra01 = 0;  // (registers the asm operands name must be initialised)
-    rk10 = rk11 = rk12 = rl10 = rl11 = rl12 = ra10 = ra11 = 0;
-    MVBA_LOAD_IDX(0, MVBA_SET0);
-    MVBA_LOAD_IDX(min(PSTEP, last0), MVBA_SET1);
-    MVBA_WAIT("s_waitcnt vmcnt(0)", MVBA_SET0);
-    MVBA_WAIT("s_waitcnt vmcnt(0)", MVBA_SET1);
-    issue_asm(lds0, MVBA_SET0);
-    MVBA_LOAD_IDX(min(2 * PSTEP, last0), MVBA_SET0);
-    issue_asm(lds0 + BUFSZ, MVBA_SET1);
-    MVBA_LOAD_IDX(min(3 * PSTEP, last0), MVBA_SET1);
-    int slot = 0;  // ring position of step s0
-    // one step: step s has landed and the indices of step s + 2 are in this set -> gather s + 2, load the indices of s + 4
-#define MVBA_SLOT_STEP(s, ...)                                                                                          \
-  if ((s) < n) { /* wave-uniform */                                                                                     \
-    MVBA_WAIT_STEP(__VA_ARGS__);                                                                                        \
-    pace_at(s);                                                                                                         \
-    const int nxt = slot == 0 ? 2 : slot - 1; /* (s + 2) % 3 */                                                         \
-    issue_asm(lds0 + nxt * BUFSZ, __VA_ARGS__);                                                                         \
-    MVBA_LOAD_IDX(min((s) + 4 * PSTEP, last0), __VA_ARGS__);                                                            \
-    compute(wbuf + slot * BUFSZ, PSTEP);                                                                                \
-    slot = slot == 2 ? 0 : slot + 1;                                                                                    \
-  }
-    for (int s0 = 0; s0 < n; s0 += 2 * PSTEP) {  // (by two: the index register sets alternate)
-      MVBA_SLOT_STEP(s0, MVBA_SET0)
-      MVBA_SLOT_STEP(s0 + PSTEP, MVBA_SET1)
+    dma_idx(0);
+    dma_idx(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_step(0);
+    dma_idx(2);
+    issue_step(min(1, last_st));
+    dma_idx(3);
+    for (int st = 0; st < nst; ++st) {
+      // step st has landed and the indices of step st + 2 are in the ring: everything but the last iteration's operations is done
+      if (DIAG) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      pace_at(st * PSTEP);
+      issue_step(st + 2);  // (past the end: the ring slot holds the indices of the clamped last step, its rows land in a buffer nobody reads)
+      dma_idx(st + 4);
+      compute(wbuf + (st % 3) * BUFSZ, PSTEP);
     }
-#undef MVBA_SLOT_STEP
-#undef MVBA_WAIT_STEP
-#undef MVBA_WAIT
-#undef MVBA_WAIT_
-#undef MVBA_LOAD_IDX
-#undef MVBA_LOAD_IDX_
-#undef MVBA_GLD
-#undef MVBA_SET0
-#undef MVBA_SET1
-    static_assert(SLOT_OPS == (DIAG ? 12 : 14), "counted wait");
+    static_assert(SLOT_OPS == (DIAG ? 7 : 8), "counted wait");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped gathers still in flight land in this wave's LDS
   }
   // J_C row i = rs_i * (record columns): f | u,v (1/f0) | t (-Jx) | omega; the same factors per column
@@ -2456,6 +2428,17 @@ __global__ __launch_bounds__(64) void k_idx_merge(long long n_waves, int nR, int
   }
 }
 
+// the slot kernel's index: one 256-byte row per step, k[21] | l[21] | a[21] | pad -- ONE LDS-DMA instruction per step
+__global__ void k_idx_interleave(long long n_steps, const int *__restrict__ st_k, const int *__restrict__ st_l, const int *__restrict__ st_a,
+                                 int *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_steps * SLOT_IDX) return;
+  const long long st = t / SLOT_IDX;
+  const int e = (int)(t - st * SLOT_IDX), which = e / PSTEP, sl = e - which * PSTEP;
+  const int *src = which == 0 ? st_k : (which == 1 ? st_l : st_a);
+  out[t] = which < 3 ? src[st * PSTEP + sl] : 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host side
@@ -2495,6 +2478,7 @@ struct mvba_handle {
   bool index_on_device = false;       // the Schur index was built by the k_idx_* kernels (nothing to upload)
   long long *d_trace = nullptr;       // -DMVBA_SLOT_TRACE builds with MVBA_SLOT_TRACE=<file>: per-wave timings of the last launch
   int4 *d_wdesc = nullptr;
+  int *d_it_x = nullptr;              // slot form: the step-major index, 64 ints per step (k[21] | l[21] | a[21] | pad)
   int *d_wunits = nullptr;
   // experiment knobs, read from the environment ONCE in mvba_create (tools/README.md lists them)
   bool pair_static = true, force_big = false;
@@ -3395,7 +3379,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       std::vector<int> live((size_t)n_rounds * nR, 0);  // waves of a (round, range) that run at all: what a pacing counter has to reach
       for (long long b = 0; b < n_waves; ++b) live[round_range(b)] += w_steps[b] > 0;
       for (long long b = 0; b < n_waves; ++b) {
-        const long long beg = w_beg[b] * PSTEP;
+        const long long beg = w_beg[b];  // first step of the wave in the step-major index
         // flags: bit 0 diagonal wave | bits 8..19 live waves of its (round, range) | bits 20..30 round
         wdesc[b] = make_int4((int)(beg & 0xffffffffLL), (int)(beg >> 32), (int)w_steps[b],
                              (w_isdiag[b / nR] ? 1 : 0) | (live[round_range(b)] << 8) | (w_round[b / nR] << 20));
@@ -3536,6 +3520,16 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       }
       if (!q_units.empty()) TRYH(hipMemcpy(h->d_q_units, q_units.data(), sizeof(int) * q_units.size(), hipMemcpyHostToDevice));
     }
+    if (h->schur_mode == SCHUR_SLOTS && h->n_slot_items) {  // the three step-major arrays -> one 256-byte row per step; they go
+      const long long n_steps = h->n_slot_items / PSTEP;
+      TRY(dmalloc(&h->d_it_x, (size_t)n_steps * SLOT_IDX));
+      hipLaunchKernelGGL(k_idx_interleave, dim3((unsigned)((n_steps * SLOT_IDX + 255) / 256)), dim3(256), 0, h->stream, n_steps, h->d_it_k, h->d_it_l,
+                         h->d_it_a, h->d_it_x);
+      TRYH(hipGetLastError());
+      TRYH(hipStreamSynchronize(h->stream));
+      hipFree(h->d_it_k); hipFree(h->d_it_l); hipFree(h->d_it_a);
+      h->d_it_k = h->d_it_l = h->d_it_a = nullptr;
+    }
     TRYH(hipMemcpy(h->d_unit_ptr, unit_ptr.data(), sizeof(int) * P1, hipMemcpyHostToDevice));
     TRYH(hipMemcpy(h->d_q_ptr, q_ptr.data(), sizeof(int) * 9, hipMemcpyHostToDevice));
     TRYH(hipMemset(h->d_q_head, 0, sizeof(int) * 64));
@@ -3595,7 +3589,7 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
-                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0};
+                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0, h->d_it_x};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -3716,7 +3710,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     if (h->schur_mode == SCHUR_SLOTS) {
       if (h->n_waves)
         hipLaunchKernelGGL(k_schur_slots, dim3(h->n_waves), dim3(64), SLOT_LDS, h->stream, h->d_wdesc,
-                           h->d_wunits, h->d_it_k, h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial,
+                           h->d_wunits, h->d_it_x, (const int *)nullptr, (const int *)nullptr, h->d_rec, h->d_PB, c, h->f0, h->d_partial,
                            h->pair_static ? nullptr : h->d_q_head, h->slot_nR, h->n_waves / std::max(1, h->slot_nR), h->d_seg_end,
                            h->slot_pace ? h->d_prog : nullptr, h->slot_nseg, h->slot_lag, h->d_trace, h->d_range_o0);
     } else if (h->n_units) {
@@ -4096,6 +4090,15 @@ int mvba_debug_read(mvba_handle *h, int32_t which, double *out, int64_t capacity
   } else if (which == MVBA_BUF_TRIAL_CAM) {
     MVBA_HIP(d2h(h->d_cam15[1 - h->cur], sizeof(double) * cnt));
   } else if (which >= MVBA_BUF_INDEX_K && which <= MVBA_BUF_INDEX_SEG) {  // the Schur index as the kernel reads it (ints, widened)
+    if (h->schur_mode == SCHUR_SLOTS && which != MVBA_BUF_INDEX_SEG) {  // one 64-int row per step: k[21] | l[21] | a[21] | pad
+      const long long n_steps = cnt / PSTEP;
+      std::vector<int> tmp((size_t)n_steps * SLOT_IDX);
+      if (cnt) MVBA_HIP(hipMemcpy(tmp.data(), h->d_it_x, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
+      const int off = which == MVBA_BUF_INDEX_K ? 0 : (which == MVBA_BUF_INDEX_L ? PSTEP : 2 * PSTEP);
+      for (long long st = 0; st < n_steps; ++st)
+        for (int sl = 0; sl < PSTEP; ++sl) out[st * PSTEP + sl] = (double)tmp[(size_t)st * SLOT_IDX + off + sl];
+      return MVBA_OK;
+    }
     const int *src = which == MVBA_BUF_INDEX_K ? h->d_it_k : (which == MVBA_BUF_INDEX_L ? h->d_it_l : (which == MVBA_BUF_INDEX_A ? h->d_it_a : h->d_seg_end));
     std::vector<int> tmp((size_t)cnt);
     if (cnt) MVBA_HIP(hipMemcpy(tmp.data(), src, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));

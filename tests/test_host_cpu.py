@@ -225,12 +225,15 @@ def test_slot_kernel_loops_carry_no_vector_memory_operation_the_counted_waits_do
         sys.path.remove(csrc)
     text = open(os.path.join(csrc, "mvba.s")).read()
     assert check_isa.check(text) == []
-    lines = check_isa.kernel_lines(text)
-    w = next(ln for ln in lines if ln.startswith("s_waitcnt vmcnt(14)"))
-    # an uncounted operation in the loop (what a spill reload looks like), a move out of a pinned register, a stray M0 write
+    # an uncounted operation in a loop (what a spill reload looks like), a register-returning load, a stray M0 write
+    w = "s_waitcnt vmcnt(8)"
+    m = re.search(r"^_ZN\d+_GLOBAL__N_113k_schur_slotsE\w*:.*?^\.Lfunc_end", text, re.S | re.M)
+    body = m.group(0)
+    assert body.count(w) == 1
     for inject, needle in (("scratch_load_dword v3, off, off offset:4", "scratch"),
-                           ("v_mov_b32_e32 v7, v153", "move reads a pinned"),
+                           ("global_load_dword v7, v2, s[4:5]", "does not count"),
+                           ("global_load_lds_dwordx4 v2, s[4:5]", "LDS-DMA operations per iteration"),
                            ("s_add_u32 m0, m0, 4", "M0 written")):
-        broken = text.replace(w, w + "\n\t" + inject, 1)
+        broken = text.replace(body, body.replace(w, w + "\n\t" + inject, 1), 1)
         errs = check_isa.check(broken)
         assert errs and any(needle in e for e in errs), (inject, errs)
