@@ -97,11 +97,15 @@ def test_full_trajectory_vs_reference(golden, name, axis, args, capsys):
     assert abs(rmse - rmse_ref) < 1e-9  # north_star: final RMSE within 1e-9 (fp64)
     assert len(E) == len(d["E_log"])  # same number of outer iterations
     assert ba._engine.n_solves == int(d["n_solves"])  # same accept/reject sequence
-    np.testing.assert_allclose(E, d["E_log"], rtol=1e-6, atol=1e-12)
-    np.testing.assert_allclose(X, d["out_X"], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(K, d["out_K"], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(R, d["out_R"], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(t, d["out_t"], rtol=0, atol=1e-6)
+    # Tolerances from the measured distance of these trajectories to the reference's (tools/trajectory_sensitivity.py,
+    # profiles/r04_trajectory_sensitivity.txt): outputs within 2e-12 (2.5e-9 for the affine scene, which stops at max_iter
+    # on a slope, not at a minimum), every E_log entry within 2e-12 relative -- asserted with a margin of 40-500x.
+    tol_out = 1e-7 if name == "affine_default" else 1e-9
+    np.testing.assert_allclose(E, d["E_log"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(X, d["out_X"], rtol=0, atol=tol_out)
+    np.testing.assert_allclose(K, d["out_K"], rtol=0, atol=tol_out)
+    np.testing.assert_allclose(R, d["out_R"], rtol=0, atol=tol_out)
+    np.testing.assert_allclose(t, d["out_t"], rtol=0, atol=tol_out)
     assert capsys.readouterr().out.startswith("Iteration 1: reprojection_error_delta = ")
     # get_log() on the device path (ref :89-98, :175-183): per outer iteration a COPY of X, R, t in the normalised
     # frame, entry 0 = the initial state; checked against the reference's own entries (first, inside, last)
@@ -112,11 +116,13 @@ def test_full_trajectory_vs_reference(golden, name, axis, args, capsys):
     if name + "_len" in tl.files:
         assert len(log) == int(tl[name + "_len"])
         for i in tl[name + "_picks"]:
-            tol = 1e-9 if i < 10 else 1e-6  # (late entries carry the trajectory's own sensitivity, as out_X above)
+            # measured: log entries within 2.3e-13 of the reference's (5.3e-11 for the affine scene's camera positions), late
+            # ones no further than early ones; 1e-10 / 1e-8 asserted
+            tol = 1e-8 if name == "affine_default" else 1e-10
             np.testing.assert_allclose(log[i]["points"], tl[f"{name}_{i}_points"], rtol=0, atol=tol)
             np.testing.assert_allclose(log[i]["basis"], tl[f"{name}_{i}_basis"], rtol=0, atol=tol)
             np.testing.assert_allclose(log[i]["pos"], tl[f"{name}_{i}_pos"], rtol=0, atol=tol)
-            assert log[i]["reprojection_error"] == pytest.approx(float(tl[f"{name}_{i}_E"]), rel=1e-6)
+            assert log[i]["reprojection_error"] == pytest.approx(float(tl[f"{name}_{i}_E"]), rel=1e-9)
 
 
 def test_default_scene_headline_numbers(golden):
