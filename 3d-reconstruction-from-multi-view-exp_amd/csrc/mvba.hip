@@ -658,7 +658,9 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
         lds_dma16(rec_at(xk[q], dslot), kb + q * (9 * PROW));
         if (!DIAG) lds_dma16(rec_at(xl[q], dslot), lb + q * (9 * PROW));
       }
+#ifndef MVBA_TIMING_NO_PB  // (timing-only build, -DMVBA_TIMING_NO_PB: what a record that also carried E^-1 would save -- wrong numbers)
       if (!DIAG) lds_dma16(pb_at(xa[0], pslot), pb_);
+#endif
     }
     if (lane < 7 * (PSTEP - 18)) {  // third chunk: rows 18..20 only (a buffer holds 21 rows)
       lds_dma16(rec_at(xk[2], dslot), kb + 2 * (9 * PROW));
@@ -679,7 +681,12 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
       const double *pb = reinterpret_cast<const double *>(pbuf + it * (16 * NPS));
       const double2 kx0 = kr[0], kx1 = kr[1], kx2 = kr[2], kf = kr[3], kw0 = kr[4], kw1 = kr[5], kw2 = kr[6];
       const double2 lx0 = lr[0], lx1 = lr[1], lx2 = lr[2];
+#ifdef MVBA_TIMING_NO_PB
+      const double i00 = DIAG ? pb[0] : 1.0, i01 = DIAG ? pb[1] : 0.0, i02 = DIAG ? pb[2] : 0.0, i11 = DIAG ? pb[3] : 1.0, i12 = DIAG ? pb[4] : 0.0,
+                   i22 = DIAG ? pb[5] : 1.0;
+#else
       const double i00 = pb[0], i01 = pb[1], i02 = pb[2], i11 = pb[3], i12 = pb[4], i22 = pb[5];
+#endif
       // h = E^-1 Jx_l^T (3x2), t = Jx_k h (2x2)
       const double h0x = i00 * lx0.x + i01 * lx1.x + i02 * lx2.x, h0y = i00 * lx0.y + i01 * lx1.y + i02 * lx2.y;
       const double h1x = i01 * lx0.x + i11 * lx1.x + i12 * lx2.x, h1y = i01 * lx0.y + i11 * lx1.y + i12 * lx2.y;
