@@ -404,9 +404,22 @@ class SvdWorkspace:
     __del__ = close
 
 
+_svd_cache = {}  # (dtype, n_cols, device) -> SvdWorkspace kept between public factorization calls
+
+
+def _svd_cache_clear():
+    for ws in _svd_cache.values():
+        ws.close()
+    _svd_cache.clear()
+
+
 def svd_factorize(Wt, n_rank, center=False, device=-1):
-    """Thin SVD of W = Wt^T through mvsvd_factorize.  Wt: (n_rows, n_cols) float32/float64,
-    C-contiguous.  Returns M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings."""
+    """Thin SVD of W = Wt^T.  Wt: (n_rows, n_cols) float32/float64, C-contiguous.
+    Returns M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings.
+    A workspace (device buffers, stream, events: `mvsvd_create`) is KEPT between calls per (dtype, n_cols, device) and grown
+    when a larger matrix arrives -- at config 5 allocating and freeing ~1 GB of device memory per call cost more than the
+    PCIe copy of the matrix; `MVBA_SVD_CACHE=0` restores the one-shot `mvsvd_factorize` (create + load + run + destroy),
+    `_svd_cache_clear()` (also at interpreter exit) releases the memory."""
     lib = load_library()
     if device_count() < 1:
         raise RuntimeError("libmvba: no HIP device visible; the SVD kernel has no CPU fallback")
@@ -414,6 +427,18 @@ def svd_factorize(Wt, n_rank, center=False, device=-1):
     if Wt.dtype not in (np.float32, np.float64):
         Wt = Wt.astype(np.float64)
     n_rows, n_cols = Wt.shape
+    if os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 2048:
+        key = (Wt.dtype.str, n_cols, int(device))
+        ws = _svd_cache.get(key)
+        if ws is None or ws.max_rows < n_rows:
+            if ws is not None:
+                ws.close()
+            if not _svd_cache:
+                import atexit
+
+                atexit.register(_svd_cache_clear)
+            ws = _svd_cache[key] = SvdWorkspace(n_rows, n_cols, Wt.dtype, device)
+        return ws.load(Wt).run(n_rank, center)
     M = np.empty((n_cols, n_rank), Wt.dtype)
     sigma = np.empty(n_cols, Wt.dtype)
     S = np.empty((n_rank, n_rows), Wt.dtype)
