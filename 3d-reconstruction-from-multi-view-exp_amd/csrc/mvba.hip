@@ -2072,8 +2072,10 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 // and it is evaluated as a directional derivative (obs_backsub: ~75 fp64 operations, the Jacobian rows
 // are never formed) -- the same linear map the Schur kernel assembled, implied columns included.
 // The trial cost is k_cost on the trial state (K6).
-template <int G>
-__global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
+// BT threads per block: 256, or 1024 once the camera table (m x 28 doubles) leaves room for one block per CU only
+// (beyond ~230 cameras: four waves per CU then; config 4's shard 0.47 -> see profiles/r04_m_*)
+template <int G, int BT = 256>
+__global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
                                                  const int *__restrict__ cam_idx, const double *__restrict__ PB,
                                                  const double *__restrict__ dxi, const double *__restrict__ X,
                                                  const double *__restrict__ cam15, double f0, double *__restrict__ Xt,
@@ -2086,7 +2088,7 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
   // G lanes per point (template).  Measured with 2 / 4 / 8 lanes: config 3 (10 observations per point)
   // 0.198 / 0.207 / 0.235 ms, config-4 shard (25 per point) 0.783 / 0.816 / 0.873 ms; one lane: 0.208
   const int s = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-  const long long a_first = (long long)blockIdx.x * (256 / G) + grp, a_step = (long long)gridDim.x * (256 / G);
+  const long long a_first = (long long)blockIdx.x * (BT / G) + grp, a_step = (long long)gridDim.x * (BT / G);
   long long nx0 = 0, nx1 = 0;  // observation range of the NEXT point of this group, requested one iteration ahead
   if (a_first < npts) { nx0 = pt_ptr[a_first]; nx1 = pt_ptr[a_first + 1]; }
   for (long long a = a_first; a < npts; a += a_step) {
@@ -2138,7 +2140,7 @@ __global__ __launch_bounds__(256) void k_backsub(long long npts, int m, const lo
 }
 
 // residual-only pass at a given state (initial cost, ref :85-87)
-__global__ __launch_bounds__(256) void k_cost(long long nobs, int m, const double *__restrict__ cam15,
+__global__ __launch_bounds__(512) void k_cost(long long nobs, int m, const double *__restrict__ cam15,
                                               const double *__restrict__ X, const int *__restrict__ obs_pt,
                                               const int *__restrict__ cam_idx, const double2 *__restrict__ xy,
                                               double f0, double *__restrict__ partials) {
@@ -2672,7 +2674,8 @@ int global_cost(mvba_handle *h, double *E) {
 int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   Timed t(h, MVBA_K_COST);
   const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
-  hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
+  // (512 threads once the camera table leaves room for two blocks per CU only: config 4's 500 cameras)
+  hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(lds > 40 * 1024 ? 512 : 256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
                      h->d_cam, h->d_xy, h->f0, h->d_partials);
   double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
   const unsigned long long seq = h->cost_seq;
@@ -3549,9 +3552,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
-  TRYH(hipFuncSetAttribute((const void *)k_backsub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_backsub<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
-  TRYH(hipFuncSetAttribute((const void *)k_backsub<8>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  for (const void *f : {(const void *)k_backsub<2>, (const void *)k_backsub<4>, (const void *)k_backsub<8>, (const void *)k_backsub<2, 1024>,
+                        (const void *)k_backsub<4, 1024>, (const void *)k_backsub<8, 1024>})
+    TRYH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
   TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
   {
@@ -3796,15 +3799,19 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const int lanes_env = h->backsub_lanes;  // (MVBA_BACKSUB_LANES at create; 0 = by mean degree)
       const double deg = (double)h->nobs / (double)h->N;
       const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
-      const int nblk = (int)std::min<long long>(4096, (h->N * G + 255) / 256);
-      auto kern = G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>);
-      hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
+      // (a camera table above half the LDS leaves one block per CU: 1024 threads then, so that the CU still holds 16 waves)
+      const bool wide = lds > 80 * 1024;
+      const int bt = wide ? 1024 : 256;
+      const int nblk = (int)std::min<long long>(wide ? 1024 : 4096, (h->N * G + bt - 1) / bt);
+      auto kern = wide ? (G == 2 ? k_backsub<2, 1024> : (G == 4 ? k_backsub<4, 1024> : k_backsub<8, 1024>))
+                       : (G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>));
+      hipLaunchKernelGGL(kern, dim3(nblk), dim3(bt), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
                          h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX);
     }
     // K6: trial cost = the residual-only pass at the trial state (fixed grid, fixed tree: deterministic)
     const size_t clds = (size_t)h->m * CAM_LDS * sizeof(double);
-    hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial], h->d_X[trial],
-                       h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
+    hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(clds > 40 * 1024 ? 512 : 256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial],
+                       h->d_X[trial], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
     double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
     const unsigned long long seq = h->cost_seq;
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, mail, seq);
