@@ -814,6 +814,8 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     // three waves per SIMD, and a spill's scratch access would be a vector-memory operation the counted waits do
     // not know about -- the records are addressed from their range's first one, mvba_create sees to that)
     static_assert(!SLOTS || !BIG, "the slot form has no 64-bit-offset build");
+    // (M0 is written in the SAME statement that uses it: it is compiler-reserved, an "m0" clobber only draws a warning, and
+    // the compiler's own M0 users -- none in this kernel: check_isa.py fails the build if one appears -- set it themselves)
     auto dma = [&](int row, unsigned slot16, const void *base, unsigned lds) {  // 16 bytes per lane: base[row * 128 + slot16] -> LDS
       const unsigned o = ((unsigned)row << 7) + slot16;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");

@@ -337,3 +337,53 @@ def test_depth_iteration_in_float32():
         assert E == pytest.approx(g.step(method, 1.0), rel=1e-3)
         np.testing.assert_allclose(ws.depth_read(), g.depths(), rtol=0, atol=2e-4)
     ws.close()
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_depth_iteration_at_a_million_points_properties(method):
+    """The device depth loop at 1,000,000 points x 8 images (fp64) -- too large for the oracle's per-point eigh in a test, so
+    size-independent properties: (i) the reprojection error a step returns equals an independent NumPy evaluation (ref :43-58) of
+    the factors the GPU SVD gives for the depths the loop held BEFORE that step (`mvsvd_run_scaled` on a second workspace);
+    (ii) depths stay positive with unit-length vectors (per point for the primary scheme, per image for the dual one, ref :118 /
+    :213); (iii) on noise-free projections the error falls from iteration to iteration; (iv) two runs are
+    bitwise identical (no atomics anywhere in the loop)."""
+    from oracle.depth_oracle import reprojection_error
+
+    n, m = 1_000_000, 8
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (n, 3))
+    x = np.empty((n, m, 3))
+    for k in range(m):
+        ph = 0.12 * k - 0.4  # cameras on an arc of radius 5 around the points, looking at the origin
+        c = 5.0 * np.array([np.sin(ph), 0.0, -np.cos(ph)])
+        R = np.array([[np.cos(ph), 0, -np.sin(ph)], [0, 1, 0], [np.sin(ph), 0, np.cos(ph)]])  # columns: right, up, forward
+        Xc = (X - c) @ R
+        x[:, k, 0], x[:, k, 1], x[:, k, 2] = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2], 1.0
+    xf = np.ascontiguousarray(x.reshape(n, 3 * m))
+    x_norm = np.linalg.norm(x, axis=2)
+
+    def run(iters):
+        ws = _mvba.SvdWorkspace(n, 3 * m, np.float64)
+        ws.load_base(xf)
+        ws.depth_begin(3)
+        Es, zs = [], [np.ones((n, m))]
+        for _ in range(iters):
+            Es.append(ws.depth_step(method, 1.0)[0])
+            zs.append(ws.depth_read())
+        ws.close()
+        return Es, zs
+
+    Es, zs = run(4)
+    chk = _mvba.SvdWorkspace(n, 3 * m, np.float64)
+    chk.load_base(xf)
+    for i in (0, 3):  # (i) first and last step
+        M, _sig, S, _tm = chk.run_scaled(zs[i], 3, method, 4)
+        assert Es[i] == pytest.approx(reprojection_error(x, M, S, 1.0), rel=1e-9)
+    chk.close()
+    xi = zs[-1] * x_norm  # (ii)
+    assert (zs[-1] > 0).all()
+    np.testing.assert_allclose(np.linalg.norm(xi, axis=1 if method == 1 else 0), 1.0, rtol=0, atol=1e-12)
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(Es, Es[1:])) and Es[-1] < 0.97 * Es[0]  # (iii) exact projections: the fit improves step by step (1.7 % per primary step here, 2.4x per dual step)
+    Es2, zs2 = run(2)  # (iv)
+    assert Es2 == Es[:2]
+    np.testing.assert_array_equal(zs2[2], zs[2])

@@ -18,9 +18,10 @@ X = rng.uniform(-1, 1, (n, 3))
 lines = []
 x = np.empty((n, m, 3))
 for k in range(m):
-    th = 0.3 * k
-    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
-    Xc = (X - np.array([0.3 * k - 1.0, 0.1 * k, -5.0])) @ R
+    ph = 0.12 * k - 0.4  # cameras on an arc of radius 5 around the points, looking at the origin
+    c = 5.0 * np.array([np.sin(ph), 0.0, -np.cos(ph)])
+    R = np.array([[np.cos(ph), 0, -np.sin(ph)], [0, 1, 0], [np.sin(ph), 0, np.cos(ph)]])  # columns: right, up, forward
+    Xc = (X - c) @ R
     x[:, k, 0], x[:, k, 1], x[:, k, 2] = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2], 1.0
 x += 1e-3 * rng.standard_normal(x.shape) * np.array([1.0, 1.0, 0.0])
 ws = _mvba.SvdWorkspace(n, 3 * m, np.float64)
