@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time check of the generated ISA of k_schur_slots (run by the Makefile on mvba.s: the build FAILS when it fails).
 
-The slot-resident Schur kernel keeps two gathers in flight with COUNTED `s_waitcnt vmcnt(N)`: every vector-memory
+The slot kernel keeps two gathers in flight with COUNTED `s_waitcnt vmcnt(N)`: every vector-memory
 operation of its loops is inline assembly the compiler knows nothing about, and N is their number per iteration.
 Correctness therefore rests on properties of the generated code that no C++ rule guarantees:
   1. the blocks of a loop (its own, wherever the compiler placed them) hold exactly N vector-memory operations -- the
@@ -17,76 +17,89 @@ Usage: check_isa.py mvba.s   (exit status 0 = all properties hold)."""
 import re
 import sys
 
-COUNTS = (("vmcnt(7)", 7), ("vmcnt(8)", 8))  # diagonal / off-diagonal loop: operations per iteration (gathers + the index row)
-VM_LOOP_OPS = ("global_load_lds_dwordx4",)
+# kernel -> (counted wait, LDS-DMA operations per iteration) of its diagonal / off-diagonal loop: the gathers + the indices
+# (a step's indices are ONE 256-byte row; a kernel that adopts the loop -- the unit form tried it in round 4 -- adds a line)
+KERNELS = {"k_schur_slots": (("vmcnt(7)", 7), ("vmcnt(8)", 8))}
+VM_LOOP_OPS = ("global_load_lds_dwordx4", "global_load_lds_dword ")
 
 
 def kernel_lines(text, name="k_schur_slots"):
-    m = re.search(r"^_ZN\d+_GLOBAL__N_1\d+" + name + r"E\w*:[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    m = re.search(r"^_ZN\d+_GLOBAL__N_1" + str(len(name)) + name + r"E\w*:[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
     if not m:
         return None
     return [ln.strip() for ln in m.group(1).splitlines()]
 
 
 def loop_blocks(lines, wait_index):
-    """Instructions of the Depth-1 blocks of the loop whose header holds the counted wait at `wait_index` (the compiler
-    annotates every block label: `.LBBx_y: ; =>This Loop Header: Depth=1` / `;   in Loop: Header=BBx_y Depth=1`; blocks it
-    moved out of line carry the annotation too), and those of its inner loops (the pacing block's poll loops)."""
-    head = max(i for i in range(wait_index + 1) if re.match(r"\.LBB\w+:.*This Loop Header: Depth=1", lines[i]))
-    name = re.match(r"\.(LBB\w+):", lines[head]).group(1)[1:]  # "BB5_35"
+    """Instructions of the Depth-1 blocks of the loop whose header holds the counted wait at `wait_index`, and those of its
+    inner loops (the pacing block's poll loops).  The compiler annotates every block label -- `.LBBx_y: ; =>This [Inner] Loop
+    Header: Depth=1` (followed by `;   Child Loop BBx_z Depth 2` lines), `;   in Loop: Header=BBx_y Depth=1` -- wherever it
+    places the block (rotated loops keep their latch ABOVE the header, cold blocks go out of line)."""
+    hdr = r"\.(LBB\w+):.*This (?:Inner )?Loop Header: Depth=1"
+    head = max(i for i in range(wait_index + 1) if re.match(hdr, lines[i]))
+    name = re.match(hdr, lines[head]).group(1)[1:]  # "BB5_35"
+    children = set()
+    for ln in lines[head + 1:]:
+        m = re.match(r";\s+Child Loop (BB\w+) Depth", ln)
+        if not m:
+            break
+        children.add(m.group(1))
     own, inner = [], []
-    cur = own
-    for i in range(head, len(lines)):
-        ln = lines[i]
-        m = re.match(r"\.LBB\w+:(.*)", ln)
+    cur = None
+    for i, ln in enumerate(lines):
+        m = re.match(r"\.(LBB\w+):(.*)", ln)
         if m:
-            note = m.group(1)
-            if i == head or f"in Loop: Header={name} Depth=1" in note:
+            label, note = m.group(1)[1:], m.group(2)
+            if i == head or f"Header={name} Depth=1" in note:
                 cur = own
-            elif "Depth=2" in note or "Depth=3" in note or "Parent Loop" in note:
-                # an inner loop of OURS only if we are still inside this loop's label range (the next Depth-1 header ends it)
+            elif label in children or any(f"Header={c} " in note for c in children):
                 cur = inner
-            elif "This Loop Header: Depth=1" in note:
-                break  # the next loop of the kernel
             else:
-                cur = None  # a block outside any loop (epilogue code placed in between)
+                cur = None
             continue
         if cur is not None:
             cur.append(ln)
     return own, inner
 
 
-def check(text):
+def check_kernel(text, name, counts):
     errs = []
-    lines = kernel_lines(text)
+    lines = kernel_lines(text, name)
     if lines is None:
-        return ["k_schur_slots not found in the ISA"]
-    for count, n_ops in COUNTS:
+        return [f"{name} not found in the ISA"]
+    for count, n_ops in counts:
         idx = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt " + count)]
         if len(idx) != 1:
-            errs.append(f"expected one `s_waitcnt {count}` (the loop's counted wait), found {len(idx)}")
+            errs.append(f"{name}: expected one `s_waitcnt {count}` (the loop's counted wait), found {len(idx)}")
             continue
         body, inner = loop_blocks(lines, idx[0])
         bad = [ln for ln in body + inner if ln.startswith(("scratch_", "buffer_"))]
         if bad:
-            errs.append(f"{count} loop: scratch / buffer access inside the loop: {bad[:3]}")
-        # one iteration = the gathers + the index row, nothing else on the loop's own blocks (the pacing block's poll and
-        # arrival are the inner loops: sc1 loads and atomics behind their own vmcnt(0))
+            errs.append(f"{name} {count} loop: scratch / buffer access inside the loop: {bad[:3]}")
+        # one iteration = the gathers + the indices, nothing else on the loop's own blocks (the slot form's pacing block --
+        # poll and arrival -- are the inner loops: sc1 loads and atomics behind their own vmcnt(0))
         straight = [ln for ln in body if ln.startswith(VM_LOOP_OPS)]
         if len(straight) != n_ops:
-            errs.append(f"{count} loop: {len(straight)} LDS-DMA operations per iteration, the wait counts {n_ops}")
+            errs.append(f"{name} {count} loop: {len(straight)} LDS-DMA operations per iteration, the wait counts {n_ops}")
         other = [ln for ln in body if ln.startswith(("global_load", "global_store", "global_atomic", "flat_")) and not ln.startswith(VM_LOOP_OPS)]
         if other:
-            errs.append(f"{count} loop: vector-memory operations the wait does not count (or that return data to a register): {other[:3]}")
+            errs.append(f"{name} {count} loop: vector-memory operations the wait does not count (or that return data to a register): {other[:3]}")
         stray = [ln for ln in inner if ln.startswith(VM_LOOP_OPS)]
         if stray:
-            errs.append(f"{count} loop: LDS-DMA inside the pacing block: {stray[:3]}")
+            errs.append(f"{name} {count} loop: LDS-DMA inside the pacing block: {stray[:3]}")
     for ln in lines:
         if re.match(r"\w+\s+m0\b", ln) and not ln.startswith("s_mov_b32 m0,"):
-            errs.append(f"M0 written outside the gathers' asm statements: {ln}")
-    vg = re.search(r"^\s*\.set _ZN\d+_GLOBAL__N_113k_schur_slotsE\w*\.num_vgpr, (\d+)", text, re.M)
+            errs.append(f"{name}: M0 written outside the gathers' asm statements: {ln}")
+    vg = re.search(r"^\s*\.set _ZN\d+_GLOBAL__N_1" + str(len(name)) + name + r"E\w*\.num_vgpr, (\d+)", text, re.M)
     if vg and int(vg.group(1)) > 168:
-        errs.append(f"k_schur_slots needs {vg.group(1)} VGPRs: more than the 168 of three waves per SIMD")
+        errs.append(f"{name} needs {vg.group(1)} VGPRs: more than the 168 of three waves per SIMD")
+    return errs
+
+
+def check(text):
+    errs = []
+    for name, counts in KERNELS.items():
+        errs += check_kernel(text, name, counts)
     return errs
 
 
@@ -96,4 +109,4 @@ if __name__ == "__main__":
         print("check_isa: " + e, file=sys.stderr)
     if errs:
         sys.exit(1)
-    print("check_isa: k_schur_slots ok (counted waits, LDS-DMA only in the loops, M0, no scratch access in the loops)")
+    print("check_isa: " + ", ".join(KERNELS) + " ok (counted waits, LDS-DMA only in the loops, M0, no scratch access in the loops)")

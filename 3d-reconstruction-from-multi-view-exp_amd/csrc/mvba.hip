@@ -2922,7 +2922,15 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     // hits on the k side) but cost a serial prologue and a 27-value tree each.  With one-wave blocks and static
     // assignment the best length is ~600 (config 3: 1.99 / 1.86 / 1.80 / 1.81 / 1.89 / 2.03 ms at 320 / 448 / 576 /
     // 640 / 768 / 1024; with four-wave blocks and atomic queues it was 768)
-    long long unit_items = 600;
+    // Round 4, re-swept where the unit form actually runs (beyond one round of the slot form): the sparser the pairs, the longer
+    // the stretch of points a unit of U items spans (U / p^2) and the further its siblings drift apart -- config 4's shard (5 %):
+    // 14.40 / 13.89 / 13.99 / 14.49 / 15.6 ms at 600 / 400 / 300 / 250 / 200 (L2 misses 743 M -> 553 M at 300, the per-unit
+    // prologue and tree eat the rest); 1 M x 200 x 10 %: 6.21 / 6.61 / 7.12 at 600 / 400 / 300; 300 k x 300 x 5 %: 1.37 / 1.23 / 1.23
+    // (profiles/r04_sweep_pairs_unit.txt).  So: 600 at one item per pair per 100 points, 400 at one per 400.
+    // (Two gathers in flight -- this form on the slot kernel's ring loop -- make it SLOWER, 15.5 ms: the wider window of
+    // points misses L2 more often, profiles/r04_sweep_pairs_ring.txt.)
+    const double pair_rate = N > 0 && P > m ? (double)(T - Tdiag) / ((double)(P - m) * (double)N) : 0.01;
+    long long unit_items = (long long)std::max(300.0, std::min(600.0, 200.0 + 4000.0 * std::sqrt(pair_rate)));
     if (const char *ev = getenv("MVBA_PAIR_UNIT")) unit_items = std::max(21, atoi(ev));
     std::vector<int> S(P), vp_ptr(P + 1, 0);
     for (long long q = 0; q < P; ++q) {
