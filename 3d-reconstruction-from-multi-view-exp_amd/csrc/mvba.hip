@@ -1605,6 +1605,94 @@ __global__ __launch_bounds__(256) void k_chol_trail32(double *M, int ld, int D, 
   }
 }
 
+// The same update for LARGE trailing matrices (round 4): k_chol_trail32 reads 64 KiB of operands per 32 x 32 tile straight
+// into registers -- every tile of a tile row re-reads that row's 32 x 128 panel from L2 -- and its waves live ~8 us for
+// 0.4 us of MFMA (profiles/r04_m_pmc_summary_config4_shard.txt: 82 % L2 hits, 53 % of the wave cycles waiting): 24-29 TFLOP/s,
+// 1.1-1.2 of the 2.8 ms of a D = 4493 solve.  Here a workgroup owns 64 x 64 of C (four waves, 32 x 32 each), the K = 128
+// columns stream through LDS in chunks of 16 (A and B chunk 8 KiB each, double-buffered, the next chunk's global loads in
+// flight during the MFMAs of this one): 32 KiB of operands per 32 x 32 of C instead of 64, one batch of C loads that lands
+// during the loop, four workgroups per CU in different phases.  First update at D = 4493: 82.8 -> 60.1 us (40 TFLOP/s);
+// a 128 x 128 tile (64 x 64 per wave, 234 VGPRs, two workgroups per CU) has twice the reuse and is SLOWER, 91 us: a lone
+// workgroup needs 27 us (8 us for its 64-value-per-lane read-modify-write of C alone) and two per CU run in lockstep.
+// Diagonal workgroups compute the full square and store the lower triangle (their upper-right wave only keeps the barriers
+// company).  Below ~200 workgroups k_chol_trail32 wins: a workgroup here lives >= 8 us, there 2-5
+// (profiles/r04_trail_block_trace.txt).
+constexpr int TB = 64, TB_KC = 16, TB_LD = TB_KC + 2;                  // tile, chunk of K, padded LDS row (144 bytes: 16-byte aligned)
+constexpr int TRAIL64_LDS = 2 * 2 * TB * TB_LD * (int)sizeof(double);  // 2 buffers x (A, B): 36,864 bytes
+__global__ __launch_bounds__(256, 4) void k_chol_trail64(double *M, int ld, int D, int jS, int jE) {
+  extern __shared__ double lds[];
+  double (*As)[TB][TB_LD] = reinterpret_cast<double (*)[TB][TB_LD]>(lds);
+  double (*Bs)[TB][TB_LD] = reinterpret_cast<double (*)[TB][TB_LD]>(lds + 2 * TB * TB_LD);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4, wy = wave >> 1, wx = wave & 1;
+  const int t = blockIdx.x;
+  int by = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while (by * (by + 1) / 2 > t) --by;
+  while ((by + 1) * (by + 2) / 2 <= t) ++by;
+  const int bx = t - by * (by + 1) / 2;
+  const int r0 = jE + TB * by, c0 = jE + TB * bx;
+  const bool idle = (bx == by) && wy == 0 && wx == 1;  // entirely above the diagonal
+  // this thread's share of a chunk: 4 consecutive doubles of one row of A and of B (four threads per 128-byte line)
+  const int prow = tid >> 2, pcol = 4 * (tid & 3);
+  const double *asrc = M + (size_t)min(r0 + prow, D) * ld + jS + pcol;
+  const double *bsrc = M + (size_t)min(c0 + prow, D) * ld + jS + pcol;
+  mvba_d4 pa = *reinterpret_cast<const mvba_d4 *>(asrc), pb = *reinterpret_cast<const mvba_d4 *>(bsrc);
+  // C (C/D layout: col = li, row = lk + 4 q): requested now, needed after the loop
+  double cv[2][2][4];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        cv[rg][cg][q] = M[(size_t)min(r0 + 16 * (2 * wy + rg) + lk + 4 * q, D) * ld + min(c0 + 16 * (2 * wx + cg) + li, D - 1)];
+  mvba_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mvba_d4{0.0, 0.0, 0.0, 0.0};
+  auto stage = [&](int b) {
+    *reinterpret_cast<mvba_d4 *>(&As[b][prow][pcol]) = pa;
+    *reinterpret_cast<mvba_d4 *>(&Bs[b][prow][pcol]) = pb;
+  };
+  stage(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < SBW / TB_KC; ++g) {
+    const int b = g & 1;
+    if (g + 1 < SBW / TB_KC) {
+      pa = *reinterpret_cast<const mvba_d4 *>(asrc + TB_KC * (g + 1));
+      pb = *reinterpret_cast<const mvba_d4 *>(bsrc + TB_KC * (g + 1));
+    }
+    if (!idle) {
+      // lane (li, lk) holds X[16 rg + li][4 lk + u] for MFMA step u: the k-permutation both operands share (see above)
+      mvba_d4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = *reinterpret_cast<const mvba_d4 *>(&As[b][16 * (2 * wy + i) + li][4 * lk]);
+        bv[i] = *reinterpret_cast<const mvba_d4 *>(&Bs[b][16 * (2 * wx + i) + li][4 * lk]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+          for (int cg = 0; cg < 2; ++cg) acc[rg][cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rg][u], bv[cg][u], acc[rg][cg], 0, 0, 0);
+    }
+    if (g + 1 < SBW / TB_KC) stage(b ^ 1);  // (read by compute(g - 1): every wave is past it since the barrier below)
+    __syncthreads();
+  }
+  if (idle) return;
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = r0 + 16 * (2 * wy + rg) + lk + 4 * q, cc = c0 + 16 * (2 * wx + cg) + li;
+        if (rr <= D && cc < D && cc <= rr) M[(size_t)rr * ld + cc] = cv[rg][cg][q] - acc[rg][cg][q];
+      }
+}
+
 // L^T x = y (y = row D of M, overwritten by x), one launch per 128-column super-block, last one
 // first.  Launch for super-block [jS, jE), given the finished x of the super-block above it
 // [jE, jE2):
@@ -2518,6 +2606,7 @@ struct mvba_handle {
   unsigned *d_bar = nullptr;
   int n_cu = 1;
   bool chol_onepass = true;  // L^T x = y as one persistent launch (MVBA_CHOL=launches: one launch per super-block)
+  int trail64_min = 200;     // trailing updates of at least this many 64 x 64 workgroups run k_chol_trail64 (MVBA_TRAIL64_MIN)
   unsigned barrier_polls = 1u << 22;  // what a device-wide barrier of that launch polls before it gives up (MVBA_CHOL_BARRIER_POLLS)
   // comm
   ncclComm_t comm = nullptr;
@@ -3573,6 +3662,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRYH(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_backsolve_all, SUPER_THREADS, BACKSOLVE_LDS));
     h->chol_onepass = per_cu >= 1 && !(getenv("MVBA_CHOL") && !strcmp(getenv("MVBA_CHOL"), "launches"));
+    if (const char *ev = getenv("MVBA_TRAIL64_MIN")) h->trail64_min = std::max(0, atoi(ev));
     if (const char *ev = getenv("MVBA_CHOL_BARRIER_POLLS")) h->barrier_polls = (unsigned)std::max(0LL, atoll(ev));
   }
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3777,8 +3867,11 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
                          h->d_Ztiles + (size_t)(jS / NB) * NB * NB, h->d_Lblk + (size_t)(jS / SBW) * SBW * SBW, h->d_flag);
       if (jE < D) {
-        const int nt32 = (D + 1 - jE + NB - 1) / NB;
-        hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
+        const int nt32 = (D + 1 - jE + NB - 1) / NB, nt64 = (D + 1 - jE + TB - 1) / TB;
+        if (jE - jS == SBW && nt64 * (nt64 + 1) / 2 >= h->trail64_min)
+          hipLaunchKernelGGL(k_chol_trail64, dim3(nt64 * (nt64 + 1) / 2), dim3(256), TRAIL64_LDS, h->stream, h->d_Ared, ld, D, jS, jE);
+        else
+          hipLaunchKernelGGL(k_chol_trail32, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, h->stream, h->d_Ared, ld, D, jS, jE);
       }
     }
     const int S = (D + SBW - 1) / SBW;
