@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "mvba_common.h"
@@ -287,8 +288,10 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
   // a block's 256 points are 18 KiB of PL and 32 KiB of PB, both contiguous: moved with coalesced
   // accesses through LDS (a thread reading its own 72-byte row / writing its own 128-byte line touches
   // 64 different lines per instruction)
-  __shared__ double s_in[256 * 9 + 8];
+  // (one buffer for both directions -- a thread takes its nine inputs into registers before anybody writes a result: 32 KiB per
+  // block = four blocks per CU instead of three at 50 KiB)
   __shared__ double2 s_out[256 * 8];
+  double *s_in = reinterpret_cast<double *>(s_out);
   const long long a0 = (long long)blockIdx.x * 256, a = a0 + threadIdx.x;
   for (long long i = a; i < nAb; i += (long long)gridDim.x * blockDim.x) Ab[i] = 0.0;
   for (long long i = a; i < nprog; i += (long long)gridDim.x * blockDim.x) prog[i] = 0;  // pacing counters of k_schur_slots
@@ -296,8 +299,11 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
   const int np = (int)min<long long>(256, npts - a0);
   for (int e = threadIdx.x; e < 9 * np; e += 256) s_in[e] = PL[9 * a0 + e];
   __syncthreads();
+  double in[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) in[i] = s_in[9 * min((int)threadIdx.x, np - 1) + i];
+  __syncthreads();
   if (threadIdx.x < np) {
-    const double *in = s_in + 9 * threadIdx.x;
     const double s = 1.0 + c;
     const double xx = in[0] * s, xy = in[1], xz = in[2], yy = in[3] * s, yz = in[4], zz = in[5] * s;
     const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
@@ -1128,9 +1134,9 @@ constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 
 __global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
-                          const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar) {
+                          const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar, int nsync) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // i in [0, D], j in [0, D)
-  if (i == 0 && j == 0) *bar = 0u;  // k_chol_backsolve_all's barrier counter
+  if (i == 0 && j < nsync) bar[j] = 0u;  // k_chol_backsolve_all's barrier counter / progress words
   if (j >= D) return;
   const int gj = keep_index(j, gauge_axis);
   if (i == D) {
@@ -1179,7 +1185,7 @@ typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 constexpr int TS = NB + 1;                               // padded LDS tile row stride
 constexpr int SUPER_THREADS = 384;  // waves 0..5: chain, workers 0..2, an idle wave (keeps the chain alone on its SIMD), worker 3
 constexpr int SUPER_LDS = (12 * NB * TS + 64 * TS + 64 * 9) * 8;  // 10 tiles + 2 Zt + Pt + panel buffer, bytes
-constexpr int BACKSOLVE_LDS = (10 * NB * TS + 4 * SBW) * 8;  // k_chol_backsolve_all: 10 tiles + y + partial sums, bytes
+constexpr int BACKSOLVE_LDS = (11 * NB * TS + 5 * SBW) * 8;  // k_chol_backsolve_all: 10 tiles + a scratch tile + y + partial sums + x, bytes
 __device__ __forceinline__ int tix(int r, int c) { return r * (r + 1) / 2 + c; }
 
 // Tile factorisation on one wave (see F above); returns false if a pivot is not positive.
@@ -1821,6 +1827,39 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // and the other workgroups' writes are visible to this wave
 }
 
+#ifdef MVBA_BS_TRACE  // timing-only build (tools/bs_trace.py): 100 MHz stamps of every chain workgroup of the last launch
+__device__ long long g_bs_trace[8 * 256];
+#define BS_STAMP(s, i) do { if (threadIdx.x == 0) g_bs_trace[8 * (s) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BS_STAMP(s, i)
+#endif
+// Point-to-point version of the same (round 4): thread 0 of a workgroup waits until a progress word has reached `target`
+// (words only grow).  No device-wide fences: an agent-scope release / acquire pair is a write-back / invalidate of the whole
+// L2 of the XCD (1.7 + 1.5 us of an 11.6 us chain step with 140 workgroups doing the same, tools/bs_trace.py), and the only
+// data that travels between workgroups here is the vector y.  So every access to y inside this kernel is an agent-scope
+// atomic (sc1: stores write through to memory, loads do not hit a stale line), a producer's waves wait for their stores
+// (workgroup-scope release = s_waitcnt vmcnt(0)), meet at a barrier, and then thread 0 stores the word; the consumer polls it,
+// passes a barrier and loads.  Gives up like grid_barrier does (and at once when somebody else already has), so the grid drains.
+template <int SLEEP>
+__device__ __forceinline__ void flow_wait(const unsigned *word, unsigned target, int *flag, unsigned max_polls) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    ++spins;
+    if (spins > max_polls || ((spins & 127u) == 0u && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8))) {
+      atomicOr(flag, 8);
+      break;
+    }
+  }
+}
+__device__ __forceinline__ void flow_post(unsigned *word, unsigned value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's sc1 stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double flow_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flow_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- L^T x = y for all super-blocks in ONE persistent launch (last block first), S - 1 device-wide
 // barriers instead of S launches.  Step s (x_{s+1} known):
 //   workgroup s ("chain" of block s)
@@ -1833,6 +1872,13 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target, int
 //       y[c] -= (rows of block s+1)^T x_{s+1} for the columns left of block s, 32 columns x 8 row
 //       chunks per workgroup: one batch of 16 loads per thread, LDS reduction.
 // One barrier per step: x_s must reach the next chain and the bulk workgroups, their updates the chain.
+// FLOW (round 4, the default): no device-wide barriers.  sync[0] = number of x blocks published (chain s posts S - s);
+// sync[1 + g] = number of x blocks applied to the 32-column group g, whose owner among the bulk workgroups applies them
+// last block first.  Chain s waits for x_{s+1} and for x_{s+2} on its own four groups -- applied a whole chain step
+// earlier, so it practically never waits for the bulk -- and a bulk workgroup for the x it is about to apply.  With nobody
+// else in a barrier the bulk can be one workgroup per group (140 at D = 4493 instead of 16: 11 us of a 14 us step were
+// their share of the matrix at ~25 GB/s each).
+template <bool FLOW>
 __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M, int ld, int D, int m, int gauge_axis,
                                                                       const double *Ztiles, const double *Lblk_all, double *dxi_full,
                                                                       int *flag, unsigned *bar, unsigned max_polls) {
@@ -1842,11 +1888,13 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
   const int S = (D + SBW - 1) / SBW;
   double (*Zs)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds);                // [4]
   double (*Ls)[NB][TS] = reinterpret_cast<double (*)[NB][TS]>(lds + 4 * NB * TS);  // [6]: in-block tile (r, c < r) at r (r - 1) / 2 + c
-  double *ys = lds + 10 * NB * TS, *part = ys + SBW;                               // part[3][SBW]; bulk: red[8][32]
+  double (*Tt)[TS] = reinterpret_cast<double (*)[TS]>(lds + 10 * NB * TS);        // scratch tile of the block inverse
+  double *ys = lds + 11 * NB * TS, *part = ys + SBW, *xs = part + 3 * SBW;         // part[3][SBW]; bulk: red[8][32], then x
   unsigned epoch = 0;
   if (bid < S) {
     // ================= chain of block s = bid
     const int s = bid, jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), ns = jE - jS, np = jE2 - jE;
+    BS_STAMP(s, 0);
     // ---- static operands, one batch.  Every load is "uniform base + one per-thread offset", so the
     // addresses live in SGPRs and the batch fits the register file.
     const double *Lblk = Lblk_all + (size_t)s * SBW * SBW;
@@ -1879,15 +1927,85 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
         const int w = tid + NT * ps;
         if (w < NB * NB) Zs[tile][w >> 5][w & 31] = zl[tile][ps];  // Ls follows Zs: tile 4 + e lands in Ls[e]
       }
+    // ---- FLOW, blocks with three chain steps of waiting ahead of them: the block's whole L_ss^-T instead of a walk over its
+    // four tiles at the step (2.8 of 5.7 us, tools/bs_trace.py).  From x_r = Z_r (y_r - sum_{c > r} L_cr^T x_c):
+    //   x_r = sum_{c >= r} W_rc y_c,  W_rr = Z_r,  W_rc = -Z_r sum_{r < k <= c} L_kr^T W_kc,
+    // six off-diagonal tiles, each two MFMA passes (the sum into the scratch tile, then -Z_r times it) on four waves, one
+    // 16 x 16 quarter each; W_rc lands in the slot of L_cr, which nobody needs any more in this order.
+    const bool inverse = FLOW && (S - 1 - s) >= 3;
+    if (inverse) {
+      __syncthreads();  // the tiles are in LDS
+      const int li = lane & 15, lk = lane >> 4, qi = (wave >> 1) & 1, qj = wave & 1;  // waves 0..3: quarter (qi, qj)
+      auto lslot = [](int tr, int tc) { return tr * (tr - 1) / 2 + tc; };
+#pragma unroll 1
+      for (int pair = 0; pair < 6; ++pair) {
+        const int r = (pair == 0) ? 2 : (pair == 1 || pair == 3) ? 1 : 0, c = (pair < 3) ? 3 : (pair < 5) ? 2 : 1;
+        if (wave < 4) {
+          mvba_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          for (int k = r + 1; k <= c; ++k) {
+            const double (*Lk)[TS] = Ls[lslot(k, r)];                         // L_kr: A = L_kr^T, A[i][kk] = L_kr[kk][i]
+            const double (*Wk)[TS] = (k == c) ? Zs[c] : Ls[lslot(c, k)];       // W_kc (already in L_ck's slot), W_cc = Z_c
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+              const int kk = 4 * g + lk;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[kk][16 * qi + li], Wk[kk][16 * qj + li], acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Tt[16 * qi + lk + 4 * q][16 * qj + li] = acc[q];
+        }
+        __syncthreads();
+        mvba_d4 w = {0.0, 0.0, 0.0, 0.0};
+        if (wave < 4) {
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const int kk = 4 * g + lk;
+            w = __builtin_amdgcn_mfma_f64_16x16x4f64(-Zs[r][16 * qi + li][kk], Tt[kk][16 * qj + li], w, 0, 0, 0);
+          }
+        }
+        __syncthreads();  // every wave has read L_cr's slot (only pair (r, c) itself uses it from here on) and the scratch tile
+        if (wave < 4) {
+          double (*Wo)[TS] = Ls[lslot(c, r)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Wo[16 * qi + lk + 4 * q][16 * qj + li] = w[q];
+        }
+        __syncthreads();
+      }
+      for (int e = tid; e < NB * TS; e += NT) (&Tt[0][0])[e] = 0.0;  // the scratch tile now stands in for the tiles left of the diagonal
+    }
+    // this thread's row of W, tile by tile (x = W y below: row tid & 127)
+    const double *wrow[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int r = (tid & (SBW - 1)) >> 5, ii = tid & 31;
+      wrow[ct] = (ct < r) ? &Tt[ii][0] : (ct == r) ? &Zs[r][ii][0] : &Ls[ct * (ct - 1) / 2 + r][ii][0];
+    }
     // ---- wait for the step
-    for (int t = S - 1; t > s; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
+    BS_STAMP(s, 1);
+    if (FLOW) {
+      if (s < S - 1) {
+        if (tid == 0) {
+          if (s + 2 <= S - 1)  // (posted a whole chain step ago: checked first, while x_{s+1} is still on its way)
+            for (int q = 0; q < 4; ++q) flow_wait<1>(bar + 1 + 4 * s + q, (unsigned)(S - (s + 2)), flag, max_polls);
+          flow_wait<0>(bar, (unsigned)(S - 1 - s), flag, max_polls);
+        }
+        BS_STAMP(s, 2);
+        __syncthreads();
+        BS_STAMP(s, 3);
+      }
+    } else
+      for (int t = S - 1; t > s; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
     // x_{s+1} (published by chain s+1 before the barrier) and y_s (complete but for the panel's share)
-    const double yv = (tid < ns) ? y[jS + tid] : 0.0;
+    const double yv = (tid < ns) ? (FLOW ? flow_load(y + jS + tid) : y[jS + tid]) : 0.0;
+    if (FLOW) {  // one sc1 load per element of x_{s+1}, the rest reads LDS (43 sc1 loads per thread: 2.2 us of a step)
+      if (tid < SBW) xs[tid] = (tid < np) ? flow_load(y + jE + tid) : 0.0;
+      __syncthreads();
+    }
     double sa = 0.0, sb = 0.0;
     if (np > 0) {
       double xv[NPN];
 #pragma unroll
-      for (int i = 0; i < NPN; ++i) xv[i] = (ph + 3 * i < np) ? y[jE + ph + 3 * i] : 0.0;
+      for (int i = 0; i < NPN; ++i) xv[i] = (ph + 3 * i < np) ? (FLOW ? xs[ph + 3 * i] : y[jE + ph + 3 * i]) : 0.0;
 #pragma unroll
       for (int i = 0; i + 1 < NPN; i += 2) {
         sa += pn[i] * xv[i];
@@ -1899,6 +2017,26 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
     __syncthreads();
     if (tid < SBW) ys[tid] = (tid < ns) ? yv - part[tid] - part[SBW + tid] - part[2 * SBW + tid] : 0.0;
     __syncthreads();
+    BS_STAMP(s, 4);
+    if (inverse) {  // x = W y: row i = tid & 127, the columns c with c % 3 == tid / 128
+      // (tile bases per thread, the column offsets compile-time constants -- one code path per third: 86 LDS reads with
+      // immediate offsets and 43 FMAs; with the addresses computed per element this took as long as the walk it replaces)
+      auto row_dot = [&](auto PH) {
+        constexpr int ph0 = decltype(PH)::value;
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NPN; ++k) {
+          const int c = ph0 + 3 * k;
+          if (c < SBW) sacc[k & 3] += wrow[c >> 5][c & 31] * ys[c];
+        }
+        return (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+      };
+      const double dot = ph == 0 ? row_dot(std::integral_constant<int, 0>{}) : ph == 1 ? row_dot(std::integral_constant<int, 1>{}) : row_dot(std::integral_constant<int, 2>{});
+      part[ph * SBW + (tid & (SBW - 1))] = dot;
+      __syncthreads();
+      if (tid < SBW) ys[tid] = part[tid] + part[SBW + tid] + part[2 * SBW + tid];
+      __syncthreads();
+    } else
     // ---- the tile chain
     for (int t = (ns + NB - 1) / NB - 1; t >= 0; --t) {
       if (wave == 0) {
@@ -1924,11 +2062,17 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
       __syncthreads();
     }
     if (tid < ns) {
-      y[jS + tid] = ys[tid];
+      if (FLOW) flow_store(y + jS + tid, ys[tid]);
+      else y[jS + tid] = ys[tid];
       dxi_full[keep_index(jS + tid, gauge_axis)] = ys[tid];
     }
     if (s == 0 && tid < 7) dxi_full[tid < 6 ? 3 + tid : 12 + gauge_axis] = 0.0;  // the removed (gauge) parameters
-    for (int t = s; t > 0; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
+    BS_STAMP(s, 5);
+    if (FLOW) {
+      if (s > 0) flow_post(bar, (unsigned)(S - s));
+      BS_STAMP(s, 6);
+    } else
+      for (int t = s; t > 0; --t) grid_barrier(bar, ++epoch * G, flag, max_polls);
     return;
   }
   // ================= bulk: at step s, columns left of block s, rows of block s+1
@@ -1937,8 +2081,14 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
   const int cj = tid & 31, ch = tid >> 5, nbulk = G - S;
   for (int s = S - 1; s >= 0; --s) {
     const int jS = s * SBW, jE = min(jS + SBW, D), jE2 = min(jE + SBW, D), np = jE2 - jE, ngrp = (jS + 31) / 32;
+    if (FLOW) {  // x_{s+1} -> the groups this workgroup owns, the rightmost (the next chain's) first
+      if (np <= 0 || bid - S >= ngrp) continue;  // (uniform; owned groups only become fewer as s falls)
+      if (tid == 0) flow_wait<8>(bar, (unsigned)(S - 1 - s), flag, max_polls);  // (the bulk has a chain step of slack: polls at leisure)
+      __syncthreads();
+    }
     if (np > 0)
-      for (int g = bid - S; g < ngrp; g += nbulk) {
+      for (int g0 = bid - S; g0 < ngrp; g0 += nbulk) {
+        const int g = FLOW ? (bid - S) + ((ngrp - 1 - (bid - S)) / nbulk) * nbulk - (g0 - (bid - S)) : g0;
         const int c = 32 * g + cj;
         double lv[16], xv[16];
 #pragma unroll
@@ -1946,9 +2096,9 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
           const int r = 16 * ch + u;
           const bool ok = act && c < jS && r < np;
           lv[u] = ok ? M[(size_t)(jE + r) * ld + c] : 0.0;
-          xv[u] = ok ? y[jE + r] : 0.0;
+          xv[u] = ok ? (FLOW ? flow_load(y + jE + r) : y[jE + r]) : 0.0;
         }
-        const double yc = (tid < 32 && c < jS) ? y[c] : 0.0;
+        const double yc = (tid < 32 && c < jS) ? (FLOW ? flow_load(y + c) : y[c]) : 0.0;
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int u = 0; u < 16; u += 2) {
@@ -1961,11 +2111,13 @@ __global__ __launch_bounds__(SUPER_THREADS) void k_chol_backsolve_all(double *M,
           double tot = 0.0;
 #pragma unroll
           for (int k = 0; k < 8; ++k) tot += red[k * 32 + cj];
-          y[c] = yc - tot;
+          if (FLOW) flow_store(y + c, yc - tot);
+          else y[c] = yc - tot;
         }
+        if (FLOW) flow_post(bar + 1 + g, (unsigned)(S - 1 - s));
         __syncthreads();
       }
-    if (s > 0) grid_barrier(bar, ++epoch * G, flag, max_polls);
+    if (!FLOW && s > 0) grid_barrier(bar, ++epoch * G, flag, max_polls);
   }
 }
 
@@ -2606,6 +2758,7 @@ struct mvba_handle {
   unsigned *d_bar = nullptr;
   int n_cu = 1;
   bool chol_onepass = true;  // L^T x = y as one persistent launch (MVBA_CHOL=launches: one launch per super-block)
+  bool chol_flow = true;     // ... synchronised point to point (MVBA_CHOL=barriers: round 2's device-wide barriers)
   int trail64_min = 200;     // trailing updates of at least this many 64 x 64 workgroups run k_chol_trail64 (MVBA_TRAIL64_MIN)
   unsigned barrier_polls = 1u << 22;  // what a device-wide barrier of that launch polls before it gives up (MVBA_CHOL_BARRIER_POLLS)
   // comm
@@ -2778,6 +2931,12 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
 }  // namespace
 
 extern "C" {
+#ifdef MVBA_BS_TRACE
+int mvba_debug_bs_trace(long long *out /* [8 * 256] */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_trace), sizeof(long long) * 8 * 256) == hipSuccess ? 0 : 1;
+}
+#endif
+
 
 const char *mvba_version(void) { return "mvba 0.2 (gfx950)"; }
 const char *mvba_last_error(void) { return g_err.c_str(); }
@@ -3581,7 +3740,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRY(dmalloc(&h->d_partials, h->n_partials));
   TRY(dmalloc(&h->d_cost, 2));
   TRY(dmalloc(&h->d_flag, 1));
-  TRY(dmalloc(&h->d_bar, 1));
+  TRY(dmalloc(&h->d_bar, 1 + 4 * (size_t)((9 * m + SBW - 1) / SBW)));  // barrier counter / progress words of the back-substitution
   TRYH(hipHostMalloc((void **)&h->h_cost, 4 * sizeof(double), hipHostMallocMapped));
   memset(h->h_cost, 0, 4 * sizeof(double));
   if (hipHostGetDevicePointer((void **)&h->d_mail, h->h_cost, 0) != hipSuccess) h->d_mail = nullptr;  // (no mapping: copy + sync as before)
@@ -3655,13 +3814,15 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
                         (const void *)k_backsub<4, 1024>, (const void *)k_backsub<8, 1024>})
     TRYH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
-  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
+  TRYH(hipFuncSetAttribute((const void *)k_chol_backsolve_all<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BACKSOLVE_LDS));
   {
     // the persistent back-substitution needs its whole grid resident: at most one workgroup per CU
     int per_cu = 0;
     TRYH(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-    TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_backsolve_all, SUPER_THREADS, BACKSOLVE_LDS));
+    TRYH(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_chol_backsolve_all<true>, SUPER_THREADS, BACKSOLVE_LDS));
     h->chol_onepass = per_cu >= 1 && !(getenv("MVBA_CHOL") && !strcmp(getenv("MVBA_CHOL"), "launches"));
+    h->chol_flow = !(getenv("MVBA_CHOL") && !strcmp(getenv("MVBA_CHOL"), "barriers"));
     if (const char *ev = getenv("MVBA_TRAIL64_MIN")) h->trail64_min = std::max(0, atoi(ev));
     if (const char *ev = getenv("MVBA_CHOL_BARRIER_POLLS")) h->barrier_polls = (unsigned)std::max(0LL, atoll(ev));
   }
@@ -3861,7 +4022,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_SOLVE);
     const int ld = h->ld;
     hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
-                       h->d_Ared, h->d_bar);
+                       h->d_Ared, h->d_bar, 1 + 4 * ((D + SBW - 1) / SBW));
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
       hipLaunchKernelGGL(k_chol_super, dim3((D + 1 - jE + 63) / 64), dim3(SUPER_THREADS), SUPER_LDS, h->stream, h->d_Ared, ld, D, jS,
@@ -3879,9 +4040,12 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       // few bulk workgroups (each then takes several column groups per step): a barrier gets dearer with
       // every workgroup -- its release/acquire writes back and invalidates that XCD's L2 for everybody on
       // it.  D = 4493: 16 bulk workgroups 2.75 ms per solve, 64: 2.93, 220: 3.24 (tools/ab_solve.py).
-      const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(std::min(h->n_cu - S, 16), ngrp)) : 0;
-      hipLaunchKernelGGL(k_chol_backsolve_all, dim3(S + nbulk), dim3(SUPER_THREADS), BACKSOLVE_LDS, h->stream, h->d_Ared, ld, D, m,
-                         h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag, h->d_bar, h->barrier_polls);
+      // (point to point -- the default since round 4 -- nobody pays for anybody else: one bulk workgroup per column group)
+      const bool flow = h->chol_flow;
+      const int ngrp = ((S - 1) * SBW + 31) / 32, nbulk = S > 1 ? std::max(1, std::min(std::min(h->n_cu - S, flow ? ngrp : 16), ngrp)) : 0;
+      hipLaunchKernelGGL(flow ? k_chol_backsolve_all<true> : k_chol_backsolve_all<false>, dim3(S + nbulk), dim3(SUPER_THREADS),
+                         BACKSOLVE_LDS, h->stream, h->d_Ared, ld, D, m, h->gauge_axis, h->d_Ztiles, h->d_Lblk, h->d_dxi, h->d_flag,
+                         h->d_bar, h->barrier_polls);
     } else
     for (int jS = ((D - 1) / SBW) * SBW; jS >= 0; jS -= SBW) {
       const int jE = std::min(jS + SBW, D), jE2 = std::min(jE + SBW, D);
