@@ -1133,22 +1133,37 @@ __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restri
 constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 
-__global__ void k_compact(int D, int ld, int m, int gauge_axis, const double *__restrict__ Afull,
-                          const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar, int nsync) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;  // i in [0, D], j in [0, D)
-  if (i == 0 && j < nsync) bar[j] = 0u;  // k_chol_backsolve_all's barrier counter / progress words
-  if (j >= D) return;
-  const int gj = keep_index(j, gauge_axis);
-  if (i == D) {
-    M[(size_t)D * ld + j] = bfull[gj];
+// One workgroup per 32 x 32 tile of the lower triangle (+ one per 256 columns of the right-hand-side row).  M[i][j], j <= i, is the
+// packed upper element (row gj, column gi): read along gi -- the packed rows are contiguous -- and written along j, through a
+// transposing LDS tile.  (Round 1-3 read it along gj, one line per element: 65 us at D = 4493.)
+__global__ __launch_bounds__(256) void k_compact(int D, int ld, int m, int gauge_axis, int nt, const double *__restrict__ Afull,
+                                                 const double *__restrict__ bfull, double *__restrict__ M, unsigned *__restrict__ bar, int nsync) {
+  __shared__ double tile[NB][NB + 1];
+  const int ntri = nt * (nt + 1) / 2, t = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (t >= ntri) {  // the right-hand side (row D) and the back-substitution's progress words
+    const int j = (t - ntri) * 256 + threadIdx.x;
+    if (j < nsync) bar[j] = 0u;
+    if (j < D) M[(size_t)D * ld + j] = bfull[keep_index(j, gauge_axis)];
     return;
   }
-  if (j > i) return;
-  const int gi = keep_index(i, gauge_axis);
-  // only the upper block triangle is stored: read (min,max) from the packed strips
-  const int r = min(gi, gj), c = max(gi, gj);
-  const int k = r / 9;
-  M[(size_t)i * ld + j] = Afull[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
+  int I = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  const int i_in = NB * I + tx;  // this thread reads column gi(i_in) of the packed rows gj(j), j = 32 J + ty + 8 q
+  const int gi = keep_index(min(i_in, D - 1), gauge_axis);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = NB * J + ty + 8 * q, gj = keep_index(min(j, D - 1), gauge_axis);
+    const int r = min(gi, gj), c = max(gi, gj), k = r / 9;  // (on a diagonal tile the upper elements read their mirror image; never stored)
+    tile[ty + 8 * q][tx] = Afull[strip_offset(k, m) + (size_t)(r - 9 * k) * (9 * (m - k)) + (c - 9 * k)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = NB * I + ty + 8 * q, j = NB * J + tx;
+    if (i < D && j <= i) M[(size_t)i * ld + j] = tile[tx][ty + 8 * q];
+  }
 }
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -4021,7 +4036,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   auto launch_solve = [&](bool onepass) {  // K4: gauge strip, blocked Cholesky, back-substitution
     Timed t(h, MVBA_K_SOLVE);
     const int ld = h->ld;
-    hipLaunchKernelGGL(k_compact, dim3((D + 255) / 256, D + 1), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, d_A, d_b,
+    const int ntc = (D + NB - 1) / NB;
+    hipLaunchKernelGGL(k_compact, dim3(ntc * (ntc + 1) / 2 + (D + 255) / 256), dim3(256), 0, h->stream, D, ld, m, h->gauge_axis, ntc, d_A, d_b,
                        h->d_Ared, h->d_bar, 1 + 4 * ((D + SBW - 1) / SBW));
     for (int jS = 0; jS < D; jS += SBW) {
       const int jE = std::min(jS + SBW, D);
