@@ -469,9 +469,12 @@ def test_config4_shape_500_cameras_8_virtual_shards():
 
 @pytest.mark.parametrize("n,m,p", [(600, 9, 0.6), (3000, 50, 0.3), (900, 300, 0.06)])
 def test_dense_solve_variants_agree(n, m, p, monkeypatch):
-    """The dense solve has two back-substitutions: one persistent launch with device-wide barriers, or
-    one launch per super-block behind MVBA_CHOL=launches (also the fallback when the persistent grid
-    could not be co-resident).  Both must give the camera step of the oracle's solve (D = 74, 443, 2693)."""
+    """The dense solve has three back-substitutions -- one persistent launch synchronised point to point (progress words,
+    sc1 atomics on y, the super-block's inverse applied at the step: the default), the same launch with round 2's
+    device-wide barriers (MVBA_CHOL=barriers), one launch per super-block (MVBA_CHOL=launches, also the fallback when the
+    persistent grid could not be co-resident) -- and two trailing updates (k_chol_trail64 from 200 workgroups up, which the
+    D = 2693 case reaches; k_chol_trail32 otherwise, everywhere with MVBA_TRAIL64_MIN set high).  All must give the camera
+    step of the oracle's solve (D = 74, 443, 2693)."""
     sc = make_scene(n, m, vis_p=p)
     g = O.OracleEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
@@ -482,25 +485,31 @@ def test_dense_solve_variants_agree(n, m, p, monkeypatch):
     ref = np.zeros(9 * m)
     ref[g.keep] = g.dxi_red
     got = {}
-    for mode in ("default", "launches"):
-        if mode == "launches":
-            monkeypatch.setenv("MVBA_CHOL", "launches")
+    modes = {"default": {}, "launches": {"MVBA_CHOL": "launches"}, "barriers": {"MVBA_CHOL": "barriers"},
+             "trail32": {"MVBA_TRAIL64_MIN": "100000000"}}
+    for mode, env in modes.items():
+        for k in ("MVBA_CHOL", "MVBA_TRAIL64_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                               sc.init_R, sc.init_t, axis=sc.axis)
         eng = ba._engine
         eng.linearize()
         eng.try_step(c)
         got[mode] = eng.debug_read("dxi")
-        assert eng.stats()["counts"]["lu_fallback"] == 0
+        assert eng.stats()["counts"]["lu_fallback"] == 0 and eng.stats()["counts"]["barrier_fallback"] == 0
         np.testing.assert_allclose(got[mode], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
-    np.testing.assert_allclose(got["launches"], got["default"], rtol=0, atol=1e-12 * np.abs(ref).max())
+    for mode in ("launches", "barriers", "trail32"):
+        np.testing.assert_allclose(got[mode], got["default"], rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
 def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_launches(monkeypatch):
-    """k_chol_backsolve_all's device-wide barriers give up after a bounded number of polls (a grid that is not
-    co-resident -- another process on the CUs -- must drain, not hang).  The step then does NOT fail: the solve is redone
-    with one launch per super-block from the intact packed system, counted in mvba_stats, and the handle stays on that
-    path.  MVBA_CHOL_BARRIER_POLLS=0 makes every barrier give up at once (D = 443: four super-blocks, three barriers)."""
+    """k_chol_backsolve_all's waits (on its progress words; device-wide barriers in the MVBA_CHOL=barriers form) give up
+    after a bounded number of polls (a grid that is not co-resident -- another process on the CUs -- must drain, not hang).
+    The step then does NOT fail: the solve is redone with one launch per super-block from the intact packed system, counted
+    in mvba_stats, and the handle stays on that path.  MVBA_CHOL_BARRIER_POLLS=0 makes every wait give up at once
+    (D = 443: four super-blocks)."""
     sc = make_scene(4000, 50, vis_p=0.2)
     args = (sc.n_points, 50, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t)
     ref = BundleAdjuster.from_observations(*args, axis=sc.axis)._engine
