@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check of the generated ISA of k_schur_slots (run by the Makefile on mvba.s: the build FAILS when it fails).
+"""Build-time check of the generated ISA of k_schur_slots and of the point-to-point back-substitution (run by the Makefile on mvba.s: the build FAILS when it fails).
 
 The slot kernel keeps two gathers in flight with COUNTED `s_waitcnt vmcnt(N)`: every vector-memory
 operation of its loops is inline assembly the compiler knows nothing about, and N is their number per iteration.
@@ -96,10 +96,46 @@ def check_kernel(text, name, counts):
     return errs
 
 
+def check_flow_posts(text):
+    """k_chol_backsolve_all<true> publishes y with sc1 stores and then a progress word (a 4-byte sc1 store by thread 0 behind
+    a workgroup barrier).  Nothing in the language orders the two -- a workgroup-scope release fence is lowered to nothing in
+    this execution mode -- so flow_post() carries an explicit `s_waitcnt vmcnt(0)`: every word store must find it between the
+    last vector-memory operation before its barrier and that barrier.  (And the kernel must stay free of the device-wide
+    fences it exists to avoid: buffer_wbl2 / buffer_inv.)"""
+    m = re.search(r"^_ZN\d+_GLOBAL__N_1\d+k_chol_backsolve_allILb1EE\w*:[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    if not m:
+        return ["k_chol_backsolve_all<true> not found in the ISA"]
+    lines = [ln.strip() for ln in m.group(1).splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith(";")]
+    errs = []
+    words = [i for i, ln in enumerate(lines) if re.match(r"global_store_dword\s.*\bsc1\b", ln)]
+    if not words:
+        errs.append("k_chol_backsolve_all<true>: no progress-word store (global_store_dword ... sc1) found")
+    for i in words:
+        bars = [k for k in range(i) if lines[k].startswith("s_barrier")]
+        if not bars:
+            errs.append(f"k_chol_backsolve_all<true>: progress-word store without a barrier before it: {lines[i]}")
+            continue
+        ok = False
+        for k in range(bars[-1] - 1, -1, -1):
+            if re.match(r"s_waitcnt\b.*vmcnt\(0\)", lines[k]):
+                ok = True
+                break
+            if lines[k].startswith(("global_", "buffer_", "flat_", "s_barrier")):
+                break
+        if not ok:
+            errs.append(f"k_chol_backsolve_all<true>: a progress word may overtake the data it announces (no s_waitcnt vmcnt(0) "
+                        f"between the last vector-memory operation and the barrier before `{lines[i]}`)")
+    if any(ln.startswith(("buffer_wbl2", "buffer_inv")) for ln in lines):
+        errs.append("k_chol_backsolve_all<true>: a device-wide fence (buffer_wbl2 / buffer_inv) crept back in")
+    return errs
+
+
 def check(text):
     errs = []
     for name, counts in KERNELS.items():
         errs += check_kernel(text, name, counts)
+    errs += check_flow_posts(text)
     return errs
 
 
@@ -109,4 +145,4 @@ if __name__ == "__main__":
         print("check_isa: " + e, file=sys.stderr)
     if errs:
         sys.exit(1)
-    print("check_isa: " + ", ".join(KERNELS) + " ok (counted waits, LDS-DMA only in the loops, M0, no scratch access in the loops)")
+    print("check_isa: " + ", ".join(KERNELS) + " ok (counted waits, LDS-DMA only in the loops, M0, no scratch access in the loops); k_chol_backsolve_all<true> ok (stores complete before their progress word, no device-wide fence)")

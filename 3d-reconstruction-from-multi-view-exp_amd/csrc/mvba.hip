@@ -1853,7 +1853,7 @@ __device__ long long g_bs_trace[8 * 256];
 // L2 of the XCD (1.7 + 1.5 us of an 11.6 us chain step with 140 workgroups doing the same, tools/bs_trace.py), and the only
 // data that travels between workgroups here is the vector y.  So every access to y inside this kernel is an agent-scope
 // atomic (sc1: stores write through to memory, loads do not hit a stale line), a producer's waves wait for their stores
-// (workgroup-scope release = s_waitcnt vmcnt(0)), meet at a barrier, and then thread 0 stores the word; the consumer polls it,
+// (s_waitcnt vmcnt(0)), meet at a barrier, and then thread 0 stores the word; the consumer polls it,
 // passes a barrier and loads.  Gives up like grid_barrier does (and at once when somebody else already has), so the grid drains.
 template <int SLEEP>
 __device__ __forceinline__ void flow_wait(const unsigned *word, unsigned target, int *flag, unsigned max_polls) {
@@ -1868,7 +1868,10 @@ __device__ __forceinline__ void flow_wait(const unsigned *word, unsigned target,
   }
 }
 __device__ __forceinline__ void flow_post(unsigned *word, unsigned value) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's sc1 stores have completed
+  // this wave's sc1 stores have COMPLETED before anybody stores the word: a workgroup-scope release fence is not enough (in
+  // this execution mode the compiler lowers it to nothing -- waves of a workgroup share their L1 -- and the word would chase
+  // the data through different L2 channels), hence the explicit wait
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -237,3 +237,12 @@ def test_slot_kernel_loops_carry_no_vector_memory_operation_the_counted_waits_do
         broken = text.replace(body, body.replace(w, w + "\n\t" + inject, 1), 1)
         errs = check_isa.check(broken)
         assert errs and any(needle in e for e in errs), (inject, errs)
+    # the point-to-point back-substitution: a progress word must not overtake the data it announces, and the kernel must
+    # stay free of device-wide fences
+    m = re.search(r"^_ZN\d+_GLOBAL__N_1\d+k_chol_backsolve_allILb1EE\w*:.*?^\.Lfunc_end", text, re.S | re.M)
+    body = m.group(0)
+    assert "s_waitcnt vmcnt(0)" in body
+    errs = check_isa.check(text.replace(body, re.sub(r"[ \t]*s_waitcnt vmcnt\(0\)[^\n]*\n", "", body), 1))
+    assert errs and any("overtake" in e for e in errs), errs
+    errs = check_isa.check(text.replace(body, body.replace("s_barrier", "buffer_wbl2 sc1\n\ts_barrier", 1), 1))
+    assert errs and any("device-wide fence" in e for e in errs), errs
