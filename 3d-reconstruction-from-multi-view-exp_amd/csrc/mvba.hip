@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 4) void k_resid_jac(long long nobs, int m, con
                                                    const int *__restrict__ tile_start, int n_tiles,
                                                    double2 *__restrict__ rec, double *__restrict__ PL,
                                                    const int *__restrict__ tile_slot, double *__restrict__ PLsplit) {
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   double *s_cam = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
@@ -2332,7 +2332,7 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 // and it is evaluated as a directional derivative (obs_backsub: ~75 fp64 operations, the Jacobian rows
 // are never formed) -- the same linear map the Schur kernel assembled, implied columns included.
 // The trial cost is k_cost on the trial state (K6).
-// BT threads per block: 256, or 1024 once the camera table (m x 28 doubles) leaves room for one block per CU only
+// BT threads per block: 256, or 1024 once the camera tables (m x 28 doubles) leave room for one block per CU only
 // (beyond ~230 cameras: four waves per CU then; config 4's shard 0.47 -> see profiles/r04_m_*)
 template <int G, int BT = 256>
 __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
@@ -2340,9 +2340,9 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
                                                  const double *__restrict__ dxi, const double *__restrict__ X,
                                                  const double *__restrict__ cam15, double f0, double *__restrict__ Xt,
                                                  double *__restrict__ dX) {
-  extern __shared__ double smem[];
-  double *s_dxi = smem, *s_cam = smem + 9 * m;
-  for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[i] = dxi[i];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *s_dxi = smem, *s_cam = smem + DXI_LDS * m;
+  for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[(i / 9) * DXI_LDS + i % 9] = dxi[i];
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   // G lanes per point (template).  Measured with 2 / 4 / 8 lanes: config 3 (10 observations per point)
@@ -2370,7 +2370,7 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
     for (int u = 0; u < PF; ++u)
       if (o0 + s + G * u < o1) {
         double t0, t1, t2;
-        obs_backsub(Xa0, Xa1, Xa2, s_cam + kk[u] * CAM_LDS, s_dxi + 9 * kk[u], f0, t0, t1, t2);
+        obs_backsub(Xa0, Xa1, Xa2, s_cam + kk[u] * CAM_LDS, s_dxi + DXI_LDS * kk[u], f0, t0, t1, t2);
         y0 += t0;
         y1 += t1;
         y2 += t2;
@@ -2378,7 +2378,7 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
     for (long long o = o0 + s + G * PF; o < o1; o += G) {
       const int k = cam_idx[o];
       double t0, t1, t2;
-      obs_backsub(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, s_dxi + 9 * k, f0, t0, t1, t2);
+      obs_backsub(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, s_dxi + DXI_LDS * k, f0, t0, t1, t2);
       y0 += t0;
       y1 += t1;
       y2 += t2;
@@ -2404,7 +2404,7 @@ __global__ __launch_bounds__(512) void k_cost(long long nobs, int m, const doubl
                                               const double *__restrict__ X, const int *__restrict__ obs_pt,
                                               const int *__restrict__ cam_idx, const double2 *__restrict__ xy,
                                               double f0, double *__restrict__ partials) {
-  extern __shared__ double s_cam[];
+  extern __shared__ __attribute__((aligned(16))) double s_cam[];
   __shared__ double s_red[16];
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
@@ -2976,9 +2976,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (p->n_points < 0 || p->n_images < 2 || p->n_obs < 0 || !p->pt_ptr || (p->n_obs && (!p->cam_idx || !p->xy)))
     return fail(MVBA_ERR_BADARG, "bad problem sizes or null arrays (need n_images >= 2)");
   if (p->gauge_axis != 0 && p->gauge_axis != 1) return fail(MVBA_ERR_BADARG, "gauge_axis must be 0 or 1");
-  // the kernels keep the whole camera table in LDS (K1: 19 doubles per camera + 8 x 8 KiB of wave
-  // tiles; back-substitution: 28 per camera): 160 KiB per workgroup caps the camera count
-  constexpr int MAX_CAMERAS = (160 * 1024 / 8 - 8 * 64 * 2 * 8 - 2) / 19;  // = 646
+  // the kernels keep the whole camera table in LDS (K1: 18 doubles per camera + 8 x 8 KiB of wave
+  // tiles; back-substitution: 28 per camera): 160 KiB per workgroup caps the camera count.  (The documented limit is
+  // round 1's, from 19 doubles per camera; 18 would admit 682.)
+  constexpr int MAX_CAMERAS = 646;
+  static_assert(MAX_CAMERAS * CAM_LDS + 8 * 64 * 2 * 8 + 2 <= 160 * 1024 / 8 && MAX_CAMERAS * (CAM_LDS + DXI_LDS) <= 160 * 1024 / 8,
+                "the camera tables of MAX_CAMERAS cameras fit one workgroup's LDS");
   if (p->n_images > MAX_CAMERAS)
     return fail(MVBA_ERR_BADARG, "n_images = " + std::to_string(p->n_images) + " exceeds the " + std::to_string(MAX_CAMERAS) +
                                      " cameras whose parameter table fits the 160 KiB of LDS of one workgroup");
@@ -3827,7 +3830,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
-  const int cam_lds = (int)((size_t)m * (CAM_LDS + 9) * sizeof(double));
+  const int cam_lds = (int)((size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double));
   for (const void *f : {(const void *)k_backsub<2>, (const void *)k_backsub<4>, (const void *)k_backsub<8>, (const void *)k_backsub<2, 1024>,
                         (const void *)k_backsub<4, 1024>, (const void *)k_backsub<8, 1024>})
     TRYH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
@@ -4081,7 +4084,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
     if (h->N) {
-      const size_t lds = (size_t)m * (CAM_LDS + 9) * sizeof(double);
+      const size_t lds = (size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double);
       const int lanes_env = h->backsub_lanes;  // (MVBA_BACKSUB_LANES at create; 0 = by mean degree)
       const double deg = (double)h->nobs / (double)h->N;
       const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
@@ -4459,7 +4462,7 @@ int mvba_project(const double *X, int64_t n_points, const double *K, const doubl
 
 int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2, double f0, double *out26) {
   if (!X3 || !cam15 || !xy2 || !out26) return fail(MVBA_ERR_BADARG, "null argument");
-  double c[CAM_LDS];
+  alignas(16) double c[CAM_LDS];
   expand_cam(cam15, f0, c);
   ObsJ J;
   obs_math(X3[0], X3[1], X3[2], c, xy2[0], xy2[1], f0, J);

@@ -23,11 +23,28 @@ inline int fail(int code, const std::string &msg) {
       return ::mvba::fail(MVBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
-// Per-camera record as the kernels keep it in LDS.  19 doubles = 38 dwords: an
-// odd multiple of 2 dwords, so lanes reading the same field of 32 different
-// cameras with ds_read_b64 hit 32 different bank pairs.
+// Per-camera record as the kernels keep it in LDS.  18 doubles = 9 quad-words, rows 16-byte aligned: a lane takes its
+// camera's row in nine 16-byte reads (ds_read_b128), and nine being odd the rows of 16 different cameras start in 16
+// different bank quads.  (Rounds 1-3: 19 doubles read 8 bytes at a time -- 27 reads per observation in the
+// back-substitution, every one of them a 32-into-32 birthday problem over the cameras of the wave's lanes: LDS 78 % busy,
+// 43 % of that in bank conflicts, profiles/r04_n_pmc_summary_config3.txt.)
 constexpr int CAM_IN = 15;   // f,u,v,t[3],R[9]  (HBM layout, [m][15])
-constexpr int CAM_LDS = 19;  // + 1/f, u/f0, v/f0
+constexpr int CAM_LDS = 18;  // + 1/f, u/f0, v/f0
+constexpr int DXI_LDS = 10;  // a camera's 9 update components, padded to five quad-words (odd again)
+
+struct alignas(16) mvba_quad { double x, y; };
+// n doubles (n even) of a 16-byte aligned row into registers, 16 bytes at a time
+template <int N>
+__host__ __device__ __forceinline__ void load_row(const double *row, double (&v)[N]) {
+  static_assert(N % 2 == 0, "rows are whole quad-words");
+  const mvba_quad *q = reinterpret_cast<const mvba_quad *>(row);
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const mvba_quad t = q[i];
+    v[2 * i] = t.x;
+    v[2 * i + 1] = t.y;
+  }
+}
 
 struct ObsJ {
   double e0, e1;
@@ -45,6 +62,9 @@ struct ObsJ {
 // 1/f, u/f0, v/f0).
 __host__ __device__ __forceinline__ void obs_math(double X0, double X1, double X2, const double *c,
                                                   double x, double y, double f0, ObsJ &J) {
+  double cc[CAM_LDS];
+  load_row(c, cc);
+  c = cc;
   const double f = c[0], u = c[1], v = c[2];
   const double d0 = X0 - c[3], d1 = X1 - c[4], d2 = X2 - c[5];
   const double *R = c + 6;
@@ -97,6 +117,11 @@ __host__ __device__ __forceinline__ void obs_math(double X0, double X1, double X
 // entries of Jc into h).  ~75 fp64 operations and one division instead of ~250 and three.
 __host__ __device__ __forceinline__ void obs_backsub(double X0, double X1, double X2, const double *c, const double *dk,
                                                      double f0, double &y0, double &y1, double &y2) {
+  double cc[CAM_LDS], dd[DXI_LDS];  // dk: a DXI_LDS row (16-byte aligned, the tenth double is padding)
+  load_row(c, cc);
+  load_row(dk, dd);
+  c = cc;
+  dk = dd;
   const double f = c[0], u = c[1], v = c[2];
   const double d0 = X0 - c[3], d1 = X1 - c[4], d2 = X2 - c[5];
   const double *R = c + 6;
@@ -125,6 +150,9 @@ __host__ __device__ __forceinline__ void obs_backsub(double X0, double X1, doubl
 // Residual only (trial cost, ref :666-677).
 __host__ __device__ __forceinline__ double obs_cost(double X0, double X1, double X2, const double *c,
                                                     double x, double y, double f0) {
+  double cc[CAM_LDS];
+  load_row(c, cc);
+  c = cc;
   const double d0 = X0 - c[3], d1 = X1 - c[4], d2 = X2 - c[5];
   const double *R = c + 6;
   const double c1 = R[0] * d0 + R[3] * d1 + R[6] * d2;
@@ -135,13 +163,12 @@ __host__ __device__ __forceinline__ double obs_cost(double X0, double X1, double
   return e0 * e0 + e1 * e1;
 }
 
-__host__ __device__ __forceinline__ void expand_cam(const double *in15, double f0, double *out19) {
+__host__ __device__ __forceinline__ void expand_cam(const double *in15, double f0, double *out18) {
 #pragma unroll
-  for (int i = 0; i < CAM_IN; ++i) out19[i] = in15[i];
-  out19[15] = 1.0 / in15[0];
-  out19[16] = in15[1] / f0;
-  out19[17] = in15[2] / f0;
-  out19[18] = 0.0;
+  for (int i = 0; i < CAM_IN; ++i) out18[i] = in15[i];
+  out18[15] = 1.0 / in15[0];
+  out18[16] = in15[1] / f0;
+  out18[17] = in15[2] / f0;
 }
 
 
