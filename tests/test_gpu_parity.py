@@ -504,6 +504,24 @@ def test_dense_solve_variants_agree(n, m, p, monkeypatch):
         np.testing.assert_allclose(got[mode], got["default"], rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
+def test_repeated_dense_solves_are_bitwise_identical():
+    """The persistent back-substitution hands y from workgroup to workgroup behind progress words (sc1 atomics, no device-wide
+    fence): an ordering fault between a word and the data it announces would show as a solve that differs from the others.
+    300 solves of one system at D = 1343 (11 super-blocks, 40 bulk workgroups) -- tools/soak_solve.py runs thousands."""
+    sc = make_scene(6000, 150, vis_p=0.08)
+    eng = BundleAdjuster.from_observations(sc.n_points, 150, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R,
+                                           sc.init_t, axis=sc.axis)._engine
+    eng.linearize()
+    E0 = eng.try_step(1e-3)
+    ref = eng.debug_read("dxi").copy()
+    assert np.isfinite(ref).all()
+    for _ in range(300):
+        assert eng.try_step(1e-3) == E0
+        assert np.array_equal(eng.debug_read("dxi"), ref)
+    counts = eng.stats()["counts"]
+    assert counts["barrier_fallback"] == 0 and counts["lu_fallback"] == 0
+
+
 def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_launches(monkeypatch):
     """k_chol_backsolve_all's waits (on its progress words; device-wide barriers in the MVBA_CHOL=barriers form) give up
     after a bounded number of polls (a grid that is not co-resident -- another process on the CUs -- must drain, not hang).
