@@ -313,6 +313,85 @@ __global__ __launch_bounds__(256) void k_rotate(const T *__restrict__ Wt, long l
   }
 }
 
+// The same product for n <= 32 columns and many rows (the preconditioning rotation of a tall matrix: 1.06 ms for 5 M x 24 with
+// the generic kernel above -- 64 x 64 output tiles of which 24 columns exist, element-wise loads -- against 0.35 ms of HBM
+// time for its 1.9 GB).  Built like k_gram_fused: a workgroup takes 128 consecutive rows per step, one contiguous byte range
+// streamed with 16-byte loads by all threads into LDS (the next step's loads in flight during this step's products); every
+// wave rotates its 32 rows on the f64 matrix cores -- A[i][k] = W[16 t + i][4 g + k] - mu, B[k][j] = V[4 g + k][16 c + j]
+// (kept in registers) -- and stores the result from the MFMA output layout.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rotate_rows(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
+                                                     const double *__restrict__ V, double *__restrict__ B) {
+  extern __shared__ double rot_lds[];
+  T *stage = reinterpret_cast<T *>(rot_lds);                       // GRAM_ROWS x n, row-major like Wt
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int nct = (n + 15) / 16, ng = (n + 3) / 4;                 // column tiles (<= 2), k-steps (<= 8)
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  double vb[2][8], mk[8];                                          // this lane's B operands and the means of its k columns
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int k = 4 * g + lk;
+    mk[g] = (mu && k < n) ? mu[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) vb[c][g] = (k < n && 16 * c + li < n) ? V[(size_t)k * n + 16 * c + li] : 0.0;
+  }
+  const long long total = n_rows * n;
+  const int nvec = GRAM_ROWS * n / VEC;
+  constexpr int MAXV = GRAM_ROWS * 32 / VEC / 256;
+  vec_t xs[MAXV];
+  auto load_step = [&](long long r0) {
+    const long long e0 = r0 * n;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int v = threadIdx.x + 256 * u;
+      const long long idx = e0 + (long long)v * VEC;
+      if (v < nvec && idx + VEC <= total) {
+        xs[u] = *reinterpret_cast<const vec_t *>(Wt + idx);
+      } else {
+#pragma unroll
+        for (int w = 0; w < VEC; ++w) xs[u][w] = (v < nvec && idx + w < total) ? Wt[idx + w] : (T)0;
+      }
+    }
+  };
+  const long long r_first = (long long)blockIdx.x * GRAM_ROWS, r_stride = (long long)gridDim.x * GRAM_ROWS;
+  if (r_first < n_rows) load_step(r_first);
+  for (long long r0 = r_first; r0 < n_rows; r0 += r_stride) {
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      const int v = threadIdx.x + 256 * u;
+      if (v < nvec) *reinterpret_cast<vec_t *>(stage + (size_t)v * VEC) = xs[u];
+    }
+    __syncthreads();
+    if (r0 + r_stride < n_rows) load_step(r0 + r_stride);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // the wave's two 16-row tiles
+      const T *rows = stage + (size_t)(wave * ROWS_PER_STEP + 16 * t + li) * n;
+      svd_d4 acc[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {  // (static indices into the operand registers; ng and nct are uniform)
+        if (g >= ng) break;
+        const int k = 4 * g + lk;
+        const double a = (k < n) ? (double)rows[k] - mk[g] : 0.0;
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[0][g], acc[0], 0, 0, 0);
+        if (nct > 1) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[1][g], acc[1], 0, 0, 0);
+      }
+      // C/D layout: col = li, row = lk + 4 q: four 128-byte row segments per store instruction, straight to HBM (through a
+      // second LDS buffer and contiguous 16-byte stores the kernel held two workgroups per CU and ran at 2.4 TB/s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long row = r0 + wave * ROWS_PER_STEP + 16 * t + lk + 4 * q;
+        if (row < n_rows) {
+          double *orow = B + row * n;
+          if (li < n) orow[li] = acc[0][q];
+          if (16 + li < n) orow[16 + li] = acc[1][q];
+        }
+      }
+    }
+    __syncthreads();  // every wave has read its rows: the staging buffer may take the next step
+  }
+}
+
 // Round-robin parallel Jacobi on the symmetric n x n matrix A (global memory), eigenvectors in V.
 // np = n rounded up to even (a phantom index np-1 == n is skipped).
 template <bool IN_LDS>  // IN_LDS: both n x n matrices live in LDS (n <= 64): latency ~100 ns instead of ~1.5 us
@@ -616,26 +695,39 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
 // range -- moved with coalesced accesses to / from a padded LDS tile (odd stride: a lane walking its own row is
 // conflict-free), so that a thread-per-row kernel neither reads nor writes memory at a row stride per lane
 // (k_scale_rows as one lane per row in global memory: ~4 ms of a 10 ms depth iteration at 5 M x 24 fp64).
+// (batches of eight independent loads, then their eight stores: written as one load and one store per trip the loop waited
+// for every load before it issued the next -- 24 round trips for a 64 x 24 tile, and the "tiled" kernels ran at 1-2.5 TB/s)
 template <typename T>
 __device__ __forceinline__ void tile_load(const T *__restrict__ src, long long base, int rows_here, int n, T *tile, int ldt, int lane) {
   const T *s = src + base * n;
-  int rr = lane / n, cc = lane - rr * n;
-  const int sr = 64 / n, sc = 64 - sr * n;
-  for (int q = lane; q < rows_here * n; q += 64) {
-    tile[rr * ldt + cc] = s[q];
-    cc += sc; rr += sr;
-    if (cc >= n) { cc -= n; ++rr; }
+  const int total = rows_here * n;
+  constexpr int U = 8;
+  for (int q0 = lane; q0 < total; q0 += 64 * U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = s[min(q0 + 64 * u, total - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 64 * u, rr = q / n;
+      if (q < total) tile[rr * ldt + (q - rr * n)] = v[u];
+    }
   }
 }
 template <typename T>
 __device__ __forceinline__ void tile_store(T *__restrict__ dst, long long base, int rows_here, int n, const T *tile, int ldt, int lane) {
   T *d = dst + base * n;
-  int rr = lane / n, cc = lane - rr * n;
-  const int sr = 64 / n, sc = 64 - sr * n;
-  for (int q = lane; q < rows_here * n; q += 64) {
-    d[q] = tile[rr * ldt + cc];
-    cc += sc; rr += sr;
-    if (cc >= n) { cc -= n; ++rr; }
+  const int total = rows_here * n;
+  constexpr int U = 8;
+  for (int q0 = lane; q0 < total; q0 += 64 * U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = min(q0 + 64 * u, total - 1), rr = q / n;
+      v[u] = tile[rr * ldt + (q - rr * n)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (q0 + 64 * u < total) d[q0 + 64 * u] = v[u];
   }
 }
 constexpr size_t TILE_MAX_BYTES = 120 * 1024;  // LDS the four tiles of a block may take (plus the small operand tables: < 160 KiB)
@@ -773,6 +865,20 @@ __global__ __launch_bounds__(256) void k_scale_rows_tiled(const T *__restrict__ 
 // first oriented to a non-negative sum (the reference inherits LAPACK's eigenvector sign there: projectively equivalent).
 // Reprojection error (:43-58) from the same M, S, per-thread sums in row order, fixed tree, fixed block order.
 
+// 1 / sqrt(u) and 1 / u from the hardware seeds and two Newton steps each (full double precision to an ulp or two): the
+// per-point kernels below take a root and up to four quotients per observation, and the library sqrt / divide expansions
+// (~35 instructions each) were most of their 1.5 ms at 5 M points x 8 images
+__device__ __forceinline__ double fast_rsqrt(double u) {
+  double r = __builtin_amdgcn_rsq(u);
+  r = r * fma(-0.5 * u * r, r, 1.5);
+  return r * fma(-0.5 * u * r, r, 1.5);
+}
+__device__ __forceinline__ double fast_rcp(double u) {
+  double r = __builtin_amdgcn_rcp(u);
+  r = fma(fma(-u, r, 1.0), r, r);
+  return fma(fma(-u, r, 1.0), r, r);
+}
+
 // dominant eigenvector of the symmetric 4 x 4 matrix g (upper triangle, row-major 10 values): cyclic Jacobi with
 // the rotations of the small solver above (same (c, s) convention), everything in registers
 __device__ __forceinline__ void dominant_eigvec4(const double (&g)[10], double (&v)[4]) {
@@ -848,7 +954,8 @@ __device__ __forceinline__ double reproj_err2(const double *u /*[3][4]*/, const 
   const double p0 = u[0] * s[0] + u[1] * s[1] + u[2] * s[2] + u[3] * s[3];
   const double p1 = u[4] * s[0] + u[5] * s[1] + u[6] * s[2] + u[7] * s[3];
   const double p2 = u[8] * s[0] + u[9] * s[1] + u[10] * s[2] + u[11] * s[3];
-  const double d0 = x0 - p0 / p2, d1 = x1 - p1 / p2, d2 = x2 - p2 / p2;
+  const double rp = fast_rcp(p2);
+  const double d0 = x0 - p0 * rp, d1 = x1 - p1 * rp, d2 = x2 - p2 * rp;
   return d0 * d0 + d1 * d1 + d2 * d2;
 }
 
@@ -877,7 +984,7 @@ __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, 
       double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int k = 0; k < m; ++k) {
         const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
         const double *u = sU + 12 * k;
         double c[4];
 #pragma unroll
@@ -894,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, 
       double nrm2 = 0.0, sum = 0.0;
       for (int k = 0; k < m; ++k) {  // xi_k = C[k] . v (unnormalised); z <- xi_k / |x_ak| for now
         const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
         const double *u = sU + 12 * k;
         double xi = 0.0;
 #pragma unroll
@@ -903,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, 
         sum += xi;
         zr[k] = (T)(xi * inv);
       }
-      const double sc = (sum < 0.0 ? -1.0 : 1.0) / sqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
+      const double sc = (sum < 0.0 ? -1.0 : 1.0) * fast_rsqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
       for (int k = 0; k < m; ++k) zr[k] = (T)((double)zr[k] * sc);
     }
     if (TILED) {
@@ -933,6 +1040,9 @@ __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, cons
   const long long a0 = (long long)blockIdx.x * rows_per_block, a1 = min(n_rows, a0 + rows_per_block);
   const double isg[4] = {is0, is1, is2, is3};
   constexpr int MAXT = 4;  // tasks per thread kept in registers (14 m <= 1024: m <= 73); beyond that the rows are re-staged per batch
+  // few images: 14 m tasks leave most of the 256 threads idle (m = 8: 112) -- the staged rows are then dealt to 2 or 4 groups
+  // of threads (row rr to group rr % nsplit), every group with its own partial (summed in group order by k_dual_reduce)
+  const int tpb = 14 * m <= 64 ? 64 : (14 * m <= 128 ? 128 : 256), nsplit = 256 / tpb, sub = (int)threadIdx.x / tpb, tl = (int)threadIdx.x % tpb;
   for (int t0 = 0; t0 < 14 * m; t0 += MAXT * 256) {
     double acc[MAXT][6];
 #pragma unroll
@@ -946,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, cons
         const int rr = e / m, k = e - rr * m;
         const T *xr = X + (r0 + rr) * n + 3 * k;
         const double x0 = (double)xr[0], x1 = (double)xr[1], x2 = (double)xr[2];
-        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
         double *d = sx + (size_t)rr * ldx + 3 * k;
         d[0] = x0 * inv; d[1] = x1 * inv; d[2] = x2 * inv;
       }
@@ -954,12 +1064,12 @@ __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, cons
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < MAXT; ++u) {
-        const int task = t0 + u * 256 + (int)threadIdx.x;
+        const int task = nsplit > 1 ? (u == 0 ? tl : 14 * m) : t0 + u * 256 + (int)threadIdx.x;
         if (task >= 14 * m) continue;
         const bool gram = task < 10 * m;
         const int k = gram ? task / 10 : (task - 10 * m) / 4;
         const int i = gram ? c_pair_i[task % 10] : (task - 10 * m) % 4, j = gram ? c_pair_j[task % 10] : i;
-        for (int rr = 0; rr < nr; ++rr) {
+        for (int rr = sub; rr < nr; rr += nsplit) {
           const double *h = sx + (size_t)rr * ldx + 3 * k;
           const double h0 = h[0], h1 = h[1], h2 = h[2], vi = sv[4 * rr + i];
           if (gram) {
@@ -974,9 +1084,9 @@ __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, cons
     }
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) {
-      const int task = t0 + u * 256 + (int)threadIdx.x;
+      const int task = nsplit > 1 ? (u == 0 ? tl : 14 * m) : t0 + u * 256 + (int)threadIdx.x;
       if (task >= 14 * m) continue;
-      double *o = part + ((size_t)blockIdx.x * 14 * m + task) * 6;
+      double *o = part + ((size_t)(blockIdx.x * nsplit + sub) * 14 * m + task) * 6;
 #pragma unroll
       for (int q = 0; q < 6; ++q) o[q] = acc[u][q];
     }
@@ -1049,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_dual_apply(const T *__restrict__ X, con
       double sum = 0.0;
       for (int k = 0; k < m; ++k) {
         const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
-        const double inv = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
         const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
         const double *w = sW + 12 * k;
         double xi = 0.0;
@@ -1160,6 +1270,11 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
   hipEventRecord(h->ev[3], st);
   if (refine) {
     if (!h->dB) MVBA_HIP(hipMalloc((void **)&h->dB, sizeof(double) * (size_t)h->max_rows * n));
+    if (n <= 32 && n % 2 == 0 && (n * sizeof(T)) % 16 == 0 && n_rows >= 4096) {  // tall and narrow: the streaming form
+      const int rgrid = (int)std::max<long long>(1, std::min<long long>(6 * 256, (n_rows + GRAM_ROWS - 1) / GRAM_ROWS));
+      const size_t rlds = (size_t)GRAM_ROWS * n * sizeof(T);
+      hipLaunchKernelGGL(k_rotate_rows<T>, dim3(rgrid), dim3(256), rlds, st, dW, n_rows, n, mu, h->dV1, h->dB);
+    } else
     hipLaunchKernelGGL(k_rotate<T>, dim3((unsigned)((n_rows + 63) / 64), (n + 63) / 64), dim3(256), 0, st, dW, n_rows, n, mu, h->dV1, h->dB);
     launch_gram<double>(h, h->dB, nullptr, chunks);
     launch_jacobi(h, h->dMr /* V2, n x n: dMr is sized for it */, 1e-15);
@@ -1282,7 +1397,8 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
   const int dual_blocks = std::max(64, std::min(DEPTH_BLOCKS, 16384 / m));  // (their partials: 14 m x 6 doubles each)
   const long long rpb = (rows + dual_blocks - 1) / dual_blocks;
   const int gblocks = (int)((rows + rpb - 1) / rpb);
-  const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + (size_t)dual_blocks * 14 * m * 6;
+  const int dsplit = 14 * m <= 64 ? 4 : (14 * m <= 128 ? 2 : 1);  // thread groups of k_dual_gram, each with its own partial
+  const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + (size_t)dual_blocks * dsplit * 14 * m * 6;
   if (!h->ddep) {
     MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));
     MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
@@ -1310,7 +1426,7 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
     MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), sizeof(double) * ((size_t)DG_ROWS * ((n | 1) + 4)), st, (const T *)h->dX, (const T *)h->dS,
                        is[0], is[1], is[2], is[3], rows, m, rpb, gpart);
-    hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 3) / 4), dim3(256), 0, st, gpart, gblocks, m, G12, colsum);
+    hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 3) / 4), dim3(256), 0, st, gpart, gblocks * dsplit, m, G12, colsum);
     hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
     hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
     if (tiled)
@@ -1367,6 +1483,8 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipMalloc((void **)&h->dpart2, sizeof(double) * (size_t)GRAM_SLICES * n_pairs * 256));
   SVD_TRY(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+  SVD_TRY(hipFuncSetAttribute((const void *)k_rotate_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  SVD_TRY(hipFuncSetAttribute((const void *)k_rotate_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   for (const void *f : {(const void *)k_scale_rows_tiled<float>, (const void *)k_scale_rows_tiled<double>, (const void *)k_depth_primary<float, true>,
                         (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
