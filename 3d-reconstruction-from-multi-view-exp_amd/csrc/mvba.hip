@@ -297,7 +297,14 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
   for (long long i = a; i < nprog; i += (long long)gridDim.x * blockDim.x) prog[i] = 0;  // pacing counters of k_schur_slots
   if (a0 >= npts) return;  // (uniform)
   const int np = (int)min<long long>(256, npts - a0);
-  for (int e = threadIdx.x; e < 9 * np; e += 256) s_in[e] = PL[9 * a0 + e];
+  {  // nine independent loads per thread, then their stores (one load and one store per trip waits for every load in turn)
+    double t[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t[i] = PL[9 * a0 + min((int)threadIdx.x + 256 * i, 9 * np - 1)];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if ((int)threadIdx.x + 256 * i < 9 * np) s_in[threadIdx.x + 256 * i] = t[i];
+  }
   __syncthreads();
   double in[9];
 #pragma unroll
@@ -2342,7 +2349,16 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
                                                  double *__restrict__ dX) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *s_dxi = smem, *s_cam = smem + DXI_LDS * m;
-  for (int i = threadIdx.x; i < 9 * m; i += blockDim.x) s_dxi[(i / 9) * DXI_LDS + i % 9] = dxi[i];
+  for (int i0 = threadIdx.x; i0 < 9 * m; i0 += 4 * blockDim.x) {  // (loads in batches of four: see k_point_inv)
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = dxi[min(i0 + u * (int)blockDim.x, 9 * m - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i < 9 * m) s_dxi[(i / 9) * DXI_LDS + i % 9] = t[u];
+    }
+  }
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
   // G lanes per point (template).  Measured with 2 / 4 / 8 lanes: config 3 (10 observations per point)
