@@ -163,7 +163,7 @@ __device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
 // Algorithmic traffic: 24 B in + 128 B out per observation + (24 in + 72 out) B per point.
 constexpr int REC = 8;  // double2 slots per observation record (128 B)
 
-__global__ __launch_bounds__(512, 4) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
+__global__ __launch_bounds__(1024, 4) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
                                                    const double *__restrict__ X,
                                                    const int *__restrict__ obs_pt,
                                                    const int *__restrict__ cam_idx,
@@ -3100,7 +3100,21 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
                                                                std::min<long long>((2048 + m - 1) / m, avg_len / 128)));
   // tuning overrides (experiments only)
   if (const char *ev = getenv("MVBA_SCHUR_THREADS")) h->schur_threads = std::max(64, std::min(768, atoi(ev) / 64 * 64));
-  if (const char *ev = getenv("MVBA_K1_THREADS")) h->k1_threads = std::max(64, std::min(512, atoi(ev) / 64 * 64));
+  {  // K1: the waves of a block share one camera table in LDS and bring 8 KiB of staging each.  Up to ~100 cameras two blocks
+    // of 8 waves fill a CU (16 waves: the register limit); beyond that ONE block fits and its size decides the occupancy --
+    // the smallest block that reaches the most waves per CU (200 cameras: 16 waves, 0.96 -> 0.70 ms at 1 M points x 10 %;
+    // 300: 14, 0.41 -> 0.32-0.37; 500: 11, config 4's shard 1.53-1.58 -> 1.32-1.36; tools/sweep_k1.sh)
+    const size_t table = (size_t)((m * CAM_LDS + 1) & ~1) * sizeof(double), per_wave = 64 * 2 * REC * sizeof(double);
+    int best_w = 8, best_tot = 0;
+    for (int w = 8; w <= 16; ++w) {
+      const size_t per = table + w * per_wave;
+      if (per > 160 * 1024) break;
+      const int tot = std::min<int>(16, (int)(160 * 1024 / per) * w);
+      if (tot > best_tot) { best_tot = tot; best_w = w; }
+    }
+    h->k1_threads = 64 * best_w;
+  }
+  if (const char *ev = getenv("MVBA_K1_THREADS")) h->k1_threads = std::max(64, std::min(1024, atoi(ev) / 64 * 64));
   if (const char *ev = getenv("MVBA_SCHUR_CHUNKS")) h->nchunks = std::max(1, atoi(ev));
   const size_t lds_cap = 150 * 1024;
   h->lseg = (int)std::min<size_t>(m, (lds_cap / 8 - 9) / 81);
@@ -3864,7 +3878,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (const char *ev = getenv("MVBA_CHOL_BARRIER_POLLS")) h->barrier_polls = (unsigned)std::max(0LL, atoll(ev));
   }
   TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
-                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + 8 * 64 * 2 * REC) * sizeof(double))));
+                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + (h->k1_threads / 64) * 64 * 2 * REC) * sizeof(double))));
   TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
 #undef TRY
 #undef TRYH
