@@ -3861,7 +3861,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   const int cam_lds = (int)((size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double));
-  for (const void *f : {(const void *)k_backsub<2>, (const void *)k_backsub<4>, (const void *)k_backsub<8>, (const void *)k_backsub<2, 1024>,
+  for (const void *f : {(const void *)k_backsub<2>, (const void *)k_backsub<4>, (const void *)k_backsub<8>, (const void *)k_backsub<2, 512>,
+                        (const void *)k_backsub<4, 512>, (const void *)k_backsub<8, 512>, (const void *)k_backsub<2, 1024>,
                         (const void *)k_backsub<4, 1024>, (const void *)k_backsub<8, 1024>})
     TRYH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
   TRYH(hipFuncSetAttribute((const void *)k_chol_super, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_LDS));
@@ -4119,11 +4120,14 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const double deg = (double)h->nobs / (double)h->N;
       const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
       // (a camera table above half the LDS leaves one block per CU: 1024 threads then, so that the CU still holds 16 waves)
-      const bool wide = lds > 80 * 1024;
-      const int bt = wide ? 1024 : 256;
-      const int nblk = (int)std::min<long long>(wide ? 1024 : 4096, (h->N * G + bt - 1) / bt);
+      // (16 waves per CU is what the registers allow: 256-thread blocks reach it while four of them fit -- tables up to 40 KiB,
+      // ~180 cameras --, 512-thread blocks while two fit, one 1024-thread block beyond)
+      const bool wide = lds > 80 * 1024, mid = !wide && lds > 40 * 1024;
+      const int bt = wide ? 1024 : (mid ? 512 : 256);
+      const int nblk = (int)std::min<long long>(4096 * 256 / bt, (h->N * G + bt - 1) / bt);
       auto kern = wide ? (G == 2 ? k_backsub<2, 1024> : (G == 4 ? k_backsub<4, 1024> : k_backsub<8, 1024>))
-                       : (G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>));
+                  : mid ? (G == 2 ? k_backsub<2, 512> : (G == 4 ? k_backsub<4, 512> : k_backsub<8, 512>))
+                        : (G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>));
       hipLaunchKernelGGL(kern, dim3(nblk), dim3(bt), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
                          h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX);
     }
