@@ -5,10 +5,10 @@
 //   K1  k_resid_jac      residual + 2x3 / 2x9 Jacobian rows per observation   (ref :291-427)
 //   K2  (fused into K1)  E_a = 2 sum JxT Jx, dP_a = 2 sum JxT e               (ref :429-469, :519-556)
 //   K3a k_point_inv      damped 3x3 inverse, v_a = E^-1 dP_a                  (ref :120-128)
-//   K3  k_schur_pairs + k_schur_reduce (k_schur_strip behind MVBA_SCHUR=strip)
+//   K3  k_schur_slots (up to ~100 cameras) / k_schur_pairs + k_schur_reduce (k_schur_strip behind MVBA_SCHUR=strip)
 //                        A = G^ - sum F^T E^-1 F,  b = sum F^T E^-1 dP - dF   (ref :132-143, :471-517, :618-664)
 //   C1  ncclAllReduce    [A|b] across point shards                            
-//   K4  k_chol_super / k_chol_trail32 / k_chol_backsolve_all (+ the k_lu_* rescue)
+//   K4  k_compact, k_chol_super / k_chol_trail64 / k_chol_trail32 / k_chol_backsolve_all (+ the k_lu_* rescue)
 //                        dense solve of the gauge-reduced system              (ref :146)
 //   K5+K6 k_backsub, k_cost  dX_a, trial state, trial cost                    (ref :152-162, :260-281, :666-677)
 // HBM layout: observations sorted by point (CSR).  The linearisation of ONE
@@ -1134,9 +1134,10 @@ __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restri
 //                 factors the 128x128 diagonal block in LDS (wave 0: tile factorisations in
 //                 registers, identity rows alongside give L^-T) and solves its own rows with
 //                 f64 MFMA (left-looking inside the super-block)
-//   k_chol_trail32  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
-//                 everything right of the super-block
-// then k_chol_backsolve_all does L^T x = y, last super-block first, from the L^-T tiles.
+//   k_chol_trail64 / k_chol_trail32  once per super-block: C -= P P^T with K = 128 on v_mfma_f64_16x16x4_f64 for
+//                 everything right of the super-block (64 x 64 tiles through LDS while there are >= 200 of them)
+// then k_chol_backsolve_all does L^T x = y, last super-block first, from the L^-T tiles, in one persistent launch whose
+// workgroups hand y to each other behind progress words.
 constexpr int NB = 32;
 constexpr int SBW = 4 * NB;
 

@@ -69,8 +69,8 @@ typedef struct mvba_stats {
   int64_t launches[16]; /* number of timed launches per kernel id                */
   int64_t n_linearize, n_try_step, n_commit;
   int64_t n_lu_fallback; /* solves that left the Cholesky path for LU with partial pivoting */
-  int64_t n_barrier_fallback; /* solves redone with one launch per super-block because a device-wide barrier of the
-                                 persistent back-substitution timed out (its grid was not co-resident)            */
+  int64_t n_barrier_fallback; /* solves redone with one launch per super-block because a wait of the persistent
+                                 back-substitution timed out (its grid was not co-resident)                        */
 } mvba_stats;
 
 const char *mvba_version(void);
