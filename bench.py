@@ -129,6 +129,44 @@ def svd_config5(rows, cols=24):
             "sigma": [float(x) for x in sig[:4]], "sigma_cpu": [float(x) for x in sig_cpu[:4]]}
 
 
+def depth_iteration(rows, m=8):
+    """The projective-depth iteration (ref lib/perspective_camera_calibration.py:79-129 primary, :166-224
+    dual) entirely on the device: `rows` points seen by m images, fp64, one `mvsvd_depth_step` per iteration -- re-weighting,
+    rank-4 factorisation, per-point 4 x 4 / per-image 12 x 12 eigenproblem, depth update, reprojection error; 8 bytes cross
+    PCIe per iteration.  Wall time of the best of five iterations per scheme and its device phases."""
+    from lib import _mvba
+
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (rows, 3))
+    x = np.empty((rows, m, 3))
+    for k in range(m):  # cameras on an arc of radius 5 around the points, looking at the origin
+        ph = 0.12 * k - 0.4
+        c = 5.0 * np.array([np.sin(ph), 0.0, -np.cos(ph)])
+        R = np.array([[np.cos(ph), 0, -np.sin(ph)], [0, 1, 0], [np.sin(ph), 0, np.cos(ph)]])
+        Xc = (X - c) @ R
+        x[:, k, 0], x[:, k, 1], x[:, k, 2] = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2], 1.0
+    x += 1e-3 * rng.standard_normal(x.shape) * np.array([1.0, 1.0, 0.0])
+    ws = _mvba.SvdWorkspace(rows, 3 * m, np.float64)
+    out = {"workload": f"{rows} points x {m} images, fp64", "pcie_bytes_per_iteration": 8}
+    try:
+        ws.load_base(x.reshape(rows, 3 * m))
+        for method, name in ((1, "primary"), (2, "dual")):
+            ws.depth_begin(3)
+            ws.depth_step(method, 1.0)  # warm-up (allocations)
+            best = None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                E, tm = ws.depth_step(method, 1.0)
+                wall = (time.perf_counter() - t0) * 1e3
+                if best is None or wall < best[0]:
+                    best = (wall, tm, E)
+            out[name] = {"wall_ms_per_iteration": best[0], "reprojection_error": best[2],
+                         "device_ms": {k: best[1][k] for k in ("gram_ms", "jacobi_ms", "refine_ms", "project_ms", "depth_ms")}}
+    finally:
+        ws.close()
+    return out
+
+
 def cpu_baseline(sc, n_images, iters=3, workers=None, config2=True):
     """The oracle (NumPy/SciPy restatement of the reference, pinned by golden vectors) timed on
     this host.  (i) config 3 ITSELF, `iters` outer LM iterations of optimize(2.0, -1.0, iters), on
@@ -274,6 +312,7 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
+    ap.add_argument("--depth-rows", type=int, default=1_000_000, help="points of the projective-depth iteration leg (0 = skip)")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1: rccl = one GPU per rank, ncclAllReduce inside libmvba (default); host = the reduced system is "
                          "staged through the host and summed over gloo, ranks may share a GPU (one-GPU rehearsal of the N>1 path)")
@@ -565,6 +604,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, n_cams, iters=args.cpu_iters, workers=args.cpu_workers)
             if args.svd_rows > 0:
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
+            if args.depth_rows > 0:
+                out["depth_iteration"] = depth_iteration(args.depth_rows)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
