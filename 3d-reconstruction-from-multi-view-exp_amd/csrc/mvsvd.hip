@@ -633,14 +633,13 @@ __global__ __launch_bounds__(JT) void k_jacobi_small(double *__restrict__ Ag, do
 constexpr int PC = 64;  // columns per LDS chunk
 template <typename T>
 __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long long n_rows, int n, int r,
-                                                 const double *__restrict__ Mr, const double *__restrict__ mu,
+                                                 const double *__restrict__ Mr4 /*[n][4], zero padded beyond r*/, const double *__restrict__ mu,
                                                  T *__restrict__ S) {
-  extern __shared__ double sm[];  // Mr [n][4] (zero padded), mu [n], then per-wave tiles of T
-  double *sM = sm, *smu = sm + 4 * (size_t)n;
+  extern __shared__ double sm[];  // (4 n doubles unused since the basis is read by scalar loads), mu [n], then per-wave tiles of T
+  double *smu = sm + 4 * (size_t)n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nc = min(n, PC), ldt = nc | 1;  // odd stride
   T *tile = reinterpret_cast<T *>(smu + n) + (size_t)wave * 64 * ldt;
-  for (int q = threadIdx.x; q < 4 * n; q += blockDim.x) sM[q] = ((q & 3) < r) ? Mr[(size_t)(q >> 2) * r + (q & 3)] : 0.0;
   for (int q = threadIdx.x; q < n; q += blockDim.x) smu[q] = mu ? mu[q] : 0.0;
   __syncthreads();
   const long long stride = (long long)gridDim.x * 256;
@@ -689,11 +688,28 @@ __global__ __launch_bounds__(256) void k_project(const T *__restrict__ Wt, long 
       }
       wave_sync();
       if (lane < rows_here) {
+        // the four basis components of a column are the same for every lane: SCALAR loads of the padded [n][4] table (a
+        // lane walking its row read them as 4 LDS broadcasts per column -- 96 of the 120 LDS reads per row at 24 columns)
         const T *tr = tile + lane * ldt;
-        for (int c = 0; c < w; ++c) {
+        typedef const double __attribute__((address_space(4))) *cptr_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        cptr_t mcs = (cptr_t)(Mr4 + 4 * (size_t)c0);
+#pragma clang diagnostic pop
+        int c = 0;
+        for (; c + 4 <= w; c += 4) {
+          double mv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mv[e] = mcs[4 * c + e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double x = (double)tr[c + u] - smu[c0 + c + u];
+            acc[0] += x * mv[4 * u]; acc[1] += x * mv[4 * u + 1]; acc[2] += x * mv[4 * u + 2]; acc[3] += x * mv[4 * u + 3];
+          }
+        }
+        for (; c < w; ++c) {
           const double x = (double)tr[c] - smu[c0 + c];
-          const double *mc = sM + 4 * (size_t)(c0 + c);
-          acc[0] += x * mc[0]; acc[1] += x * mc[1]; acc[2] += x * mc[2]; acc[3] += x * mc[3];
+          acc[0] += x * mcs[4 * c]; acc[1] += x * mcs[4 * c + 1]; acc[2] += x * mcs[4 * c + 2]; acc[3] += x * mcs[4 * c + 3];
         }
       }
       wave_sync();
@@ -1333,8 +1349,8 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
   for (int g0 = 0; g0 < n_rank; g0 += 4) {
     const int rg = std::min(4, n_rank - g0);
     for (int c = 0; c < n; ++c)
-      for (int i = 0; i < rg; ++i) Mg[(size_t)c * rg + i] = Mr[(size_t)c * n_rank + g0 + i];
-    MVBA_HIP(hipMemcpyAsync(h->dMr, Mg.data(), sizeof(double) * (size_t)n * rg, hipMemcpyHostToDevice, st));
+      for (int i = 0; i < 4; ++i) Mg[(size_t)c * 4 + i] = i < rg ? Mr[(size_t)c * n_rank + g0 + i] : 0.0;  // [n][4], zero padded
+    MVBA_HIP(hipMemcpyAsync(h->dMr, Mg.data(), sizeof(double) * (size_t)n * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_project<T>, dim3(pgrid), dim3(256), plds, st, dW, n_rows, n, rg, h->dMr, mu, (T *)h->dS + (size_t)g0 * n_rows);
     MVBA_HIP(hipStreamSynchronize(st));  // Mg is reused by the next group
   }
