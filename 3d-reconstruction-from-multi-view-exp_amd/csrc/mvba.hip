@@ -280,6 +280,7 @@ __global__ void k_sum_split(int n_split, const int4 *__restrict__ splits /* poin
 // PB[a][PBS] = inverse of E_a with diagonal*(1+c) (6 unique), v_a = E^-1 dP_a (3), pad: one
 // 128-byte line per point, so a gather of the inverse touches one 64-byte sector.
 constexpr int PBS = 16;
+constexpr int PACE_STRIDE = 32;  // ints between two pacing counters: one 128-byte line each (they are hammered by ~300 waves)
 // Also clears the packed [A|b] the Schur kernel is about to accumulate into (one launch less on
 // the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
@@ -563,7 +564,20 @@ constexpr int UNIT_STRIDE = 104;                // doubles per unit partial
 constexpr int SLOT_BUF = PSTEP * (2 * PROW + 3 * 16);  // slot form: one packed staging buffer (k rows, l rows, 48-byte point rows)
 constexpr int SLOT_IDX = 64;                    // slot form: ints per step in the index (k[21] | l[21] | a[21] | pad): ONE 256-byte DMA row
 constexpr int SLOT_IDX_RING = 3;                // ... staged three steps deep in LDS
+#if defined(MVBA_HREC_TIMING)
+#ifndef MVBA_HREC_NBUF
+#define MVBA_HREC_NBUF 3
+#endif
+constexpr int PAIRS_LDS = 2 * (PSTEP * (80 + 144));
+constexpr int SLOT_LDS = MVBA_HREC_NBUF * (PSTEP * (80 + 144)) + MVBA_HREC_NBUF * SLOT_IDX * 4;  // (timing build of the h-in-the-record variant)
+#else
+constexpr int PAIRS_LDS = 2 * PWAVE_LDS;  // the unit form: two staging buffers per wave
 constexpr int SLOT_LDS = 3 * SLOT_BUF + SLOT_IDX_RING * SLOT_IDX * 4;  // three staging buffers + the index ring per wave: 17,904 B, nine waves per CU
+// (LDS is handed out in 512-byte granules: 9 x 17,920 = 161,280 of the 163,840 bytes.  16 bytes are all a wave could still have --
+// with 48 more, a CU holds eight waves, the range's 284 are no longer all resident and the launch spends 6 ms in pacing time-outs:
+// profiles/r05_pace_poll.txt)
+static_assert(9 * ((SLOT_LDS + 511) / 512 * 512) <= 160 * 1024, "nine waves per CU");
+#endif
 
 __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_uniform) {
   __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
@@ -581,12 +595,11 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_unifo
 // would land on the next chunk's first slot).
 // Pacing of the slot-resident form (k_schur_slots): `seg_end[j]` = the step at which this wave has left segment j of
 // its point range, `prog[j]` = how many waves of the range have left segment j, `need` = how many there are.
-constexpr int PACE_STRIDE = 32;  // ints between two pacing counters: one 128-byte line each (they are hammered by ~300 waves)
 struct SlotPace {
   const int *seg_end;
   int *prog;
   int need, nseg, lag;
-  long long *trace;  // diagnostic builds (-DMVBA_SLOT_TRACE): 8 words per wave
+  long long *trace;  // diagnostic builds (-DMVBA_SLOT_TRACE): 16 words per wave (8 general + the loop's phase sums in shader cycles)
 };
 // SLOTS (the slot-resident form below, k_schur_slots): the 21 item rows of a step belong to 21 DIFFERENT lists, each
 // 3-lane slot keeps its own block for the whole run and writes it to its own partial (`out` is then the array of
@@ -721,6 +734,11 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
         }
       }
       const double2 s0v = lr[sel0], s1v = lr[sel1], s2v = lr[sel2];
+#if defined(MVBA_KO_VALU)  // (timing-only knock-out: every LDS read stays, the arithmetic shrinks to a handful of additions)
+      acc[0][0] += (t00 + t01) + (t10 + t11) + (kf.x + kf.y) + (kw0.x + kw0.y) + (kw1.x + kw1.y) + (kw2.x + kw2.y) + (s0v.x + s0v.y) + (s1v.x + s1v.y) + (s2v.x + s2v.y) + w0 + w1;
+      if (false)
+#endif
+      {
       const double sx[3] = {s0v.x, al12 * s1v.x + bx1, al12 * s2v.x};
       const double sy[3] = {s0v.y, al12 * s1v.y, al12 * s2v.y + bx1};
 #pragma unroll
@@ -742,6 +760,7 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
           else dg[q] += sx[q] * sx[q] + sy[q] * sy[q];
           rb[q] += sx[q] * w0 + sy[q] * w1;
         }
+      }
       }
     }
     // the LDS reads above are complete (their values were consumed) before this buffer is refilled
@@ -830,12 +849,23 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     // (M0 is written in the SAME statement that uses it: it is compiler-reserved, an "m0" clobber only draws a warning, and
     // the compiler's own M0 users -- none in this kernel: check_isa.py fails the build if one appears -- set it themselves)
     auto dma = [&](int row, unsigned slot16, const void *base, unsigned lds) {  // 16 bytes per lane: base[row * 128 + slot16] -> LDS
+#if defined(MVBA_KO_GATHER)  // (timing-only knock-out: every gather fetches row 0 of its array -- one line, always in L2 -- instead of its row)
+      row = 0;
+#endif
       const unsigned o = ((unsigned)row << 7) + slot16;
+#if defined(MVBA_KO_DMA)     // (timing-only knock-out: no record / point-row gather at all; the counted waits are adjusted below)
+      (void)o; (void)base; (void)lds;
+#else
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");
+#endif
     };
     const unsigned lane16 = (unsigned)min(lane, 15) << 4;
     auto dma_idx = [&](int st) {  // the 256-byte index row of step st -> ring slot st % 3 (lanes 0..15, 16 bytes each)
+#if defined(MVBA_KO_IDX)  // (timing-only knock-out: always the wave's FIRST index row -- in L2 after the first touch -- instead of a new line from HBM)
+      const int *src = xbase + (size_t)min(st & 1, last_st) * SLOT_IDX;
+#else
       const int *src = xbase + (size_t)min(st, last_st) * SLOT_IDX;  // wave-uniform
+#endif
       const unsigned dst = ldsx0 + (unsigned)(st % SLOT_IDX_RING) * (SLOT_IDX * 4);
       if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(dst) : "memory");
     };
@@ -879,15 +909,42 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     dma_idx(2);
     issue_step(min(1, last_st));
     dma_idx(3);
+#ifdef MVBA_SLOT_TRACE  // where a step's cycles go: one s_memtime stamp (with its own lgkmcnt(0): ~40 cycles) between the phases
+#define TR_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, tA, tB, tC, tD, tE, tF, tL0, tL1;
+    TR_STAMP(tL0);
+#else
+#define TR_STAMP(v)
+#endif
     for (int st = 0; st < nst; ++st) {
+      TR_STAMP(tA);
       // step st has landed and the indices of step st + 2 are in the ring: everything but the last iteration's operations is done
+#if defined(MVBA_KO_DMA)
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#else
       if (DIAG) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+      TR_STAMP(tB);
       pace_at(st * PSTEP);
+      TR_STAMP(tC);
       issue_step(st + 2);  // (past the end: the ring slot holds the indices of the clamped last step, its rows land in a buffer nobody reads)
+      TR_STAMP(tD);
       dma_idx(st + 4);
+      TR_STAMP(tE);
       compute(wbuf + (st % 3) * BUFSZ, PSTEP);
+#ifdef MVBA_SLOT_TRACE
+      TR_STAMP(tF);
+      ph0 += tB - tA; ph1 += tC - tB; ph2 += tD - tC; ph3 += tE - tD; ph4 += tF - tE;
+#endif
     }
+#ifdef MVBA_SLOT_TRACE
+    TR_STAMP(tL1);
+    if (pace.trace && lane == 0) {
+      pace.trace[8] = (long long)ph0; pace.trace[9] = (long long)ph1; pace.trace[10] = (long long)ph2; pace.trace[11] = (long long)ph3;
+      pace.trace[12] = (long long)ph4; pace.trace[13] = (long long)(tL1 - tL0);
+    }
+#endif
     static_assert(SLOT_OPS == (DIAG ? 7 : 8), "counted wait");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped gathers still in flight land in this wave's LDS
   }
@@ -956,6 +1013,11 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
   }
 }
 
+#if defined(MVBA_HREC_TIMING)  // timing-only variant of both kernels (round 5, measured and not built: see the header)
+#include "mvba_hrec_timing.h"
+#endif
+
+
 // One wave per block: a wave works alone, and in a wider block its LDS and wave slots stay taken until
 // the block's slowest wave has finished (4 waves per block: 1.945 ms, 2: 1.92, 1: 1.89 at config 3).
 template <bool BIG>
@@ -998,8 +1060,13 @@ __device__ __forceinline__ void schur_pairs_wave(const int4 *__restrict__ units,
   const long long beg = ((long long)ud_y << 32) | (unsigned)ud_x;
   const int n = ud_z, cam_k = (int)((unsigned)ud_w >> 16), cam_l = ud_w & 0xffff;
   double *out = partial + (size_t)u * UNIT_STRIDE;
+#if defined(MVBA_HREC_TIMING)  // timing-only (wrong numbers): slot 7 of the records stands in for the residual array
+  if (cam_k == cam_l) schur_pairs_unit_hrec<true, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, rec + 7, PB, c, 1.0 / f0, out);
+  else schur_pairs_unit_hrec<false, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, rec + 7, PB, c, 1.0 / f0, out);
+#else
   if (cam_k == cam_l) schur_pairs_unit<true, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
   else schur_pairs_unit<false, BIG>(wbuf, lane, beg, n, it_k, it_l, it_a, rec, PB, c, 1.0 / f0, out);
+#endif
 }
 
 #define MVBA_PAIRS_ARGS                                                                                                   \
@@ -1065,19 +1132,30 @@ __device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc,
   // the record indices of the step rows are RELATIVE to the range's first observation: the 32-bit byte offsets of the
   // gathers then span a range's records (4 GiB = 33.5 M observations per range), not the scene's
   const double2 *rec_r = rec + (size_t)as_const(range_o0)[r] * REC;
-  SlotPace pace{nullptr, nullptr, 0, 0, 2, trace ? trace + 8 * (size_t)bid : nullptr};
+  SlotPace pace{nullptr, nullptr, 0, 0, 2, trace ? trace + 16 * (size_t)bid : nullptr};
   if (prog) pace = SlotPace{seg_end + (size_t)bid * nseg, prog + ((size_t)round * nR + r) * nseg * PACE_STRIDE, live, nseg, lag, pace.trace};
+#if defined(MVBA_HREC_TIMING)  // timing-only: today's records read with the new access pattern and arithmetic -- wrong numbers
+  const double2 *res_r = rec_r + 7;  // (the residual "array": slot 7 of the records, 128-byte stride -> dma16 takes row << 4 ... see below)
+  if (flags & 1)
+    schur_slots_hrec<true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, rec_r, res_r, PB, c, 1.0 / f0, partial, su, pace, 0);
+  else
+    schur_slots_hrec<false>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, rec_r, res_r, PB, c, 1.0 / f0, partial, su, pace, 0);
+#else
   if (flags & 1)
     schur_pairs_unit<true, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec_r, PB, c, 1.0 / f0, partial, su, pace);
   else
     schur_pairs_unit<false, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec_r, PB, c, 1.0 / f0, partial, su, pace);
+#endif
 }
 #define MVBA_SLOTS_ARGS                                                                                                  \
   const int4 *__restrict__ wdesc, const int *__restrict__ wunits, const int *__restrict__ it_k, const int *__restrict__ it_l, \
       const int *__restrict__ it_a, const double2 *__restrict__ rec, const double *__restrict__ PB, double c, double f0,  \
       double *__restrict__ partial, int *__restrict__ head, int nR, int wpr, const int *__restrict__ seg_end,            \
       int *__restrict__ prog, int nseg, int lag, long long *__restrict__ trace, const long long *__restrict__ range_o0
-__global__ __launch_bounds__(64, 3) void k_schur_slots(MVBA_SLOTS_ARGS) {
+#ifndef MVBA_SLOT_WAVES_PER_SIMD
+#define MVBA_SLOT_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(64, MVBA_SLOT_WAVES_PER_SIMD) void k_schur_slots(MVBA_SLOTS_ARGS) {
   schur_slots_wave(wdesc, wunits, it_k, it_l, it_a, rec, PB, c, f0, partial, head, nR, wpr, seg_end, prog, nseg, lag, trace, range_o0);
 }
 
@@ -3233,8 +3311,13 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     long long unit_items = (long long)std::max(300.0, std::min(600.0, 200.0 + 4000.0 * std::sqrt(pair_rate)));
     if (const char *ev = getenv("MVBA_PAIR_UNIT")) unit_items = std::max(21, atoi(ev));
     std::vector<int> S(P), vp_ptr(P + 1, 0);
+    // (MVBA_SLOT_DIAG_SCALE: the sub-lists of a pair much larger than the target -- the diagonal pairs -- are cut shorter by
+    // this factor: a diagonal step costs more instructions than an off-diagonal one, and the pace of a range is its slowest wave's)
+    double big_scale = 1.0;
+    if (const char *ev = getenv("MVBA_SLOT_DIAG_SCALE")) big_scale = std::max(0.25, std::min(4.0, atof(ev)));
     for (long long q = 0; q < P; ++q) {
       S[q] = (int)std::max<long long>(1, std::min<long long>(256, (cnt[q] + target / 2) / target));
+      if (S[q] >= 2 && big_scale != 1.0) S[q] = (int)std::max(1.0, std::min(256.0, std::floor((double)cnt[q] / (double)target * big_scale + 0.5)));
       vp_ptr[q + 1] = vp_ptr[q] + S[q];
     }
     const int VP = vp_ptr[P];
@@ -3248,7 +3331,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     // (ng + 1 times) instead of once per unit that needs it (the unit form: ~16 times from beyond the L2 at m = 500).
     int n_cu_dev = 256;
     hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, h->device);
+#if defined(MVBA_HREC_TIMING)
+    const int xcd_waves = std::max(1, n_cu_dev / 8) * std::min(160 * 1024 / SLOT_LDS, 4 * MVBA_SLOT_WAVES_PER_SIMD);
+#else
     const int xcd_waves = std::max(1, n_cu_dev / 8) * (160 * 1024 / SLOT_LDS);  // 9 waves of 17,136 B of LDS per CU
+#endif
     int ng = 1, G = m, max_round_waves = 0;
     auto round_waves = [&](int G_, int g1, int g2) {  // waves (of 21 lists) of round (g1, g2): diagonal + off-diagonal
       long long ld = 0, lo = 0;
@@ -3814,7 +3901,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRY(dmalloc(&h->d_q_ptr, 9)); TRY(dmalloc(&h->d_q_units, q_units.size())); TRY(dmalloc(&h->d_q_head, 64));
     TRY(dmalloc(&h->d_wdesc, wdesc.size())); TRY(dmalloc(&h->d_wunits, wunits.size()));
 #ifdef MVBA_SLOT_TRACE
-    if (getenv("MVBA_SLOT_TRACE")) { TRY(dmalloc(&h->d_trace, 8 * std::max<size_t>(1, wdesc.size()))); TRYH(hipMemset(h->d_trace, 0, 64 * std::max<size_t>(1, wdesc.size()))); }
+    if (getenv("MVBA_SLOT_TRACE")) { TRY(dmalloc(&h->d_trace, 16 * std::max<size_t>(1, wdesc.size()))); TRYH(hipMemset(h->d_trace, 0, 128 * std::max<size_t>(1, wdesc.size()))); }
 #endif
     if (!h->index_on_device) TRY(dmalloc(&h->d_seg_end, seg_end.size()));
     TRY(dmalloc(&h->d_prog, (size_t)h->slot_rounds * h->slot_nR * std::max(1, h->slot_nseg) * PACE_STRIDE));
@@ -3895,13 +3982,13 @@ void mvba_destroy(mvba_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
 #ifdef MVBA_SLOT_TRACE
   if (h->d_trace && getenv("MVBA_SLOT_TRACE")) {
-    std::vector<long long> tr(8 * (size_t)h->n_waves);
+    std::vector<long long> tr(16 * (size_t)h->n_waves);
     hipMemcpy(tr.data(), h->d_trace, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost);
     if (FILE *f = fopen(getenv("MVBA_SLOT_TRACE"), "w")) {
-      fprintf(f, "# block t0 t1 wait blocked polls hwid xcc nsteps (100 MHz ticks); nR=%d lag=%d nseg=%d\n", h->slot_nR, h->slot_lag, h->slot_nseg);
+      fprintf(f, "# block t0 t1 wait blocked polls hwid xcc nsteps (100 MHz ticks) | shader cycles summed over the steps: vmcnt-wait pace gather-issue index-dma compute loop-total - -; nR=%d lag=%d nseg=%d\n", h->slot_nR, h->slot_lag, h->slot_nseg);
       for (int b = 0; b < h->n_waves; ++b) {
         fprintf(f, "%d", b);
-        for (int q = 0; q < 8; ++q) fprintf(f, " %lld", tr[8 * (size_t)b + q]);
+        for (int q = 0; q < 16; ++q) fprintf(f, " %lld", tr[16 * (size_t)b + q]);
         fprintf(f, "\n");
       }
       fclose(f);
@@ -4040,7 +4127,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     } else if (h->n_units) {
       const bool stat = h->pair_static;
       hipLaunchKernelGGL(big ? k_schur_pairs_big : k_schur_pairs, dim3(stat ? 8 * h->q_max : h->n_units), dim3(64),
-                         2 * PWAVE_LDS, h->stream, h->d_units, h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k,
+                         PAIRS_LDS, h->stream, h->d_units, h->d_q_ptr, h->d_q_units, stat ? nullptr : h->d_q_head, h->d_it_k,
                          h->d_it_l, h->d_it_a, h->d_rec, h->d_PB, c, h->f0, h->d_partial);
     }
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,

@@ -5,8 +5,10 @@ import sys
 
 import numpy as np
 
-a = np.loadtxt(sys.argv[1], comments="#").reshape(-1, 9)
-a = a[a[:, 8] > 0]
+raw = np.loadtxt(sys.argv[1], comments="#")
+raw = raw[raw[:, 8] > 0]
+a = raw[:, :9]
+ph = raw[:, 9:15] if raw.shape[1] >= 15 else None
 blk = a[:, 0].astype(int)
 t0, t1, wait, blocked, polls, hwid, xcc, nsteps = (a[:, i] for i in range(1, 9))
 base = t0.min()
@@ -31,3 +33,14 @@ for n in sorted(set(nsimd)):
 for x in range(8):
     m = blk % 8 == x
     print(f"  range {x}: end median {np.median((t1[m] - base) / 100):7.0f} max {((t1[m] - base) / 100).max():7.0f}  wait median {np.median(wait[m]) / 100:6.0f}")
+
+if ph is not None and ph[:, 5].max() > 0:  # phase sums of the loop in shader cycles (round 5)
+    names = ("vmcnt wait", "pacing", "index reads + gather issue", "index DMA", "LDS reads + arithmetic")
+    per = ph[:, :5] / nsteps[:, None]
+    tot = ph[:, 5] / nsteps
+    print(f"shader cycles per step (median over the waves; loop total {np.median(tot):.0f}, = {np.median(ph[:, 5] / (dur * 1e3)) * 1e3:.0f} MHz against the 100 MHz clock):")
+    for i, nme in enumerate(names):
+        print(f"  {nme:28s} {np.median(per[:, i]):7.0f}   p10 {np.percentile(per[:, i], 10):7.0f}  p90 {np.percentile(per[:, i], 90):7.0f}")
+    for n in sorted(set(nsimd)):
+        m = nsimd == n
+        print(f"  waves on a SIMD holding {n}: " + "  ".join(f"{nme.split()[0]} {np.median(per[m, i]):.0f}" for i, nme in enumerate(names)))
