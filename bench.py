@@ -101,7 +101,144 @@ def cpu_info():
         blas = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in threadpool_info()]
     except Exception:  # noqa: BLE001
         pass
-    return {"host_cpus": os.cpu_count(), "cpu_model": model, "blas": blas, "numpy": np.__version__}
+    cores = set()
+    try:  # physical cores = distinct (socket, core id) pairs
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip() and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count()
+    quota = None
+    try:  # cgroup v2 CPU quota of this container, in CPUs
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"host_cpus": os.cpu_count(), "physical_cores": len(cores) or None, "affinity_cpus": affinity, "cgroup_quota_cpus": quota,
+            "cpu_model": model, "blas": blas, "numpy": np.__version__}
+
+
+def default_cpu_workers(info):
+    """One oracle worker per PHYSICAL core this process may use (NumPy's kernels are single-threaded; SMT siblings add nothing
+    to an fp64 stream): min(physical cores, affinity mask, cgroup quota), at most 128 processes."""
+    n = info.get("physical_cores") or info.get("host_cpus") or 1
+    n = min(n, info.get("affinity_cpus") or n)
+    if info.get("cgroup_quota_cpus"):
+        n = min(n, max(1, int(info["cgroup_quota_cpus"])))
+    return max(1, min(int(n), 128))
+
+
+def schur_roofline(info, n_obs, k3_ms, n_cu):
+    """`roofline` object of K3.  `achieved` / `frac` price SURVEY 8d's algorithmic 192 B/observation against the
+    HBM peak, as the contract asks; `bound` says what actually bounds the kernel form that ran: the slot form is held back by
+    what a CU can do per step beside its L2 -> LDS row gathers (see `gather`; round 5's knock-out builds: no single resource,
+    profiles/r05_k3_knockouts.txt), the unit form by the fabric -- its L2 MISSES run at the line-fill rate of the chip
+    (`traffic` = 12-13 x the algorithmic bytes at 500 cameras)."""
+    k3_bytes = 192 * n_obs
+    k3_ach = k3_bytes / (k3_ms * 1e-3) / 1e9
+    k3_name = {"strip": "k_schur_strip", "pairs": "k_schur_pairs", "slots": "k_schur_slots"}[info["kernel"]]
+    k3_traffic, k3_src = pmc_traffic(k3_name, n_obs)
+    gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
+    flops = info["items"] * 3 * 96 * 2
+    gather_rows = 3 * (info["slot_rows"] or info["items"])
+    rows_rate = gather_rows / (k3_ms * 1e3) / n_cu
+    slot_form = info["kernel"] == "slots"
+    roof = {"kernel": k3_name + " (K3)",
+            "bound": "l2_gather" if slot_form else "fabric_line_fills",
+            "bound_note": ("not HBM: the CU's L2 -> LDS row gathers beside LDS reads and fp64 issue (see `gather`); `achieved` / `frac` price "
+                           "SURVEY 8d's algorithmic 192 B/observation against the HBM peak as the contract asks" if slot_form else
+                           "not HBM bandwidth on algorithmic bytes: the kernel's L2 misses (l-side records, half of the point rows) are line "
+                           "fills from the Infinity Cache / HBM at the chip's line-fill rate, `traffic` = 12-13 x the algorithmic bytes; "
+                           "`achieved` / `frac` price SURVEY 8d's 192 B/observation against the HBM peak as the contract asks"),
+            "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,
+            "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
+            "traffic_GBs": (k3_traffic / (k3_ms * 1e-3) / 1e9 if k3_traffic else None),
+            "algorithmic_bytes_per_launch": k3_bytes, "algorithmic_bytes_per_obs": 192, "avg_launch_ms": k3_ms,
+            "items": info["items"], "units": info["units"],
+            "slot_rows_incl_padding": info["slot_rows"] or None,
+            "gather": {"row_gathers_per_launch": gather_rows, "rows_per_us_per_cu": rows_rate,
+                       "ceiling_rows_per_us_per_cu": GATHER_CEILING_ROWS_PER_US_PER_CU,
+                       "frac": rows_rate / GATHER_CEILING_ROWS_PER_US_PER_CU, "compute_units": n_cu,
+                       "definition": "3 row gathers per step row (padding rows included) / launch time / CUs; ceiling: "
+                                     "profiles/r03_microbench_gather_rows.txt (717-759 rows/us per CU from L2)"},
+            "gathered_bytes_per_launch": gather, "gather_GBs": gather / (k3_ms * 1e-3) / 1e9,
+            "fp64_tflops": flops / (k3_ms * 1e-3) / 1e12,
+            "frac_of_fp64_valu_peak": flops / (k3_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+    return roof
+
+
+def allreduce_model(n_cams, ranks=8):
+    """C1 of an N-rank job priced on the xGMI fabric (7 links x ~153 GB/s per GPU, point to point; MI355X_MICROARCH.md): what the
+    first real SCALE run's `allreduce.ms_per_solve` can be compared with.  ring = one ring over one link per neighbour (each rank
+    sends 2 (N-1)/N of the buffer); direct = reduce-scatter + all-gather with every rank talking to its N-1 peers at once."""
+    nbytes = 8 * (81 * n_cams * (n_cams + 1) // 2 + 9 * n_cams)
+    link = 153e9
+    return {"bytes_per_solve": nbytes, "ranks": ranks, "link_GBs": link / 1e9,
+            "ring_one_link_ms": 2 * (ranks - 1) / ranks * nbytes / link * 1e3,
+            "direct_all_links_ms": 2 * (nbytes / ranks) / link * 1e3,
+            "note": "bandwidth terms only (no launch / latency terms: +10-30 us per collective); every rank then solves the reduced system redundantly"}
+
+
+def config4_shard_leg(device, steps=3):
+    """BASELINE config 4's per-GPU shard (1.25 M points x 500 cameras x 5 % = 1/8 of the scene, no exchange) on the one GPU of an
+    N = 1 run: the only hardware evidence for the multi-GPU configuration while no 8-GPU node runs the bench.  One warm-up LM
+    iteration, then `steps` iterations with every phase timed (hipEvents on the engine's stream)."""
+    import torch
+
+    from lib.bundle_adjustment import BundleAdjuster, LevenbergMarquardt
+    from lib.synthetic import make_scene
+
+    n_pts, n_cams, vis = 1_250_000, 500, 0.05
+    t0 = time.perf_counter()
+    sc = make_scene(n_pts, n_cams, vis_p=vis)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ba = BundleAdjuster.from_observations(sc.n_points, n_cams, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t,
+                                          axis=sc.axis, device=device)
+    t_create = time.perf_counter() - t0
+    eng = ba._engine
+    try:
+        lm = LevenbergMarquardt(eng, 2.0)
+        E0 = lm.E
+        eng.set_profiling(True)
+        lm.carry_on(lm.iterate()[0])  # warm-up (creates the events)
+        eng.reset_stats()
+        s0 = eng.n_solves
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            E_ = lm.iterate()[0]
+            lm.carry_on(E_)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        solves = eng.n_solves - s0
+        info = eng.schur_info()
+        n_cu = int(torch.cuda.get_device_properties(device).multi_processor_count)
+        per_solve = {k: v["ms"] / max(solves, 1) for k, v in st.items() if k != "counts"}
+        k3_ms = st["schur"]["ms"] / max(st["schur"]["launches"], 1)
+        return {"workload": f"BASELINE config 4, ONE of its 8 point shards: {n_pts} points x {n_cams} cameras x {vis:.0%} = {sc.n_obs} observations, "
+                            f"D = {9 * n_cams - 7}, on one GPU (no exchange); {steps} LM iterations after one warm-up",
+                "steps": steps, "inner_solves": solves, "ms_per_step": dt / steps * 1e3, "ms_per_inner_solve": dt / max(solves, 1) * 1e3,
+                "it_per_s": steps / dt, "kernel_ms_per_solve": per_solve,
+                "rmse_start": float(np.sqrt(E0 / sc.n_obs)), "rmse_end": float(np.sqrt(E_ / sc.n_obs)),
+                "scene_generation_s": t_gen, "engine_create_s": t_create,
+                "roofline": schur_roofline(info, sc.n_obs, k3_ms, n_cu),
+                "counts": st["counts"],
+                "allreduce_model_8_gpus": allreduce_model(n_cams, 8)}
+    finally:
+        eng.close()
 
 
 def svd_config5(rows, cols=24):
@@ -178,7 +315,7 @@ def cpu_baseline(sc, n_images, iters=3, workers=None, config2=True):
     from oracle.ba_parallel import ShardedOracle
 
     info = cpu_info()
-    workers = int(workers or min(os.cpu_count() or 1, 64))
+    workers = int(workers or default_cpu_workers(info))
     X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
     t0 = time.perf_counter()
     g = ShardedOracle(sc.n_points, n_images, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis, X, sc.init_K[:, 0, 0],
@@ -193,7 +330,9 @@ def cpu_baseline(sc, n_images, iters=3, workers=None, config2=True):
         "value": iters / (t2 - t1), "unit": "it/s", "cores": workers, "kind": "port",
         "sample": f"oracle/ba_parallel.py: the WHOLE config-3 scene ({sc.n_points} points x {n_images} cameras, {sc.n_obs} "
                   f"observations), optimize(2.0, -1.0, {iters}) = {iters} outer LM iterations / {solves} solves in {t2 - t1:.1f} s on "
-                  f"{workers} worker processes (one point shard each, 1 BLAS thread per worker); setup {t1 - t0:.1f} s not counted",
+                  f"{workers} worker processes = {workers} of the host's {info.get('physical_cores')} physical cores ({info.get('host_cpus')} "
+                  f"logical CPUs, affinity {info.get('affinity_cpus')}, cgroup quota {info.get('cgroup_quota_cpus')}); one point shard and 1 BLAS "
+                  f"thread per worker; setup {t1 - t0:.1f} s not counted",
         "rmse_start": float(np.sqrt(E0 / sc.n_obs)), "rmse_end": float(np.sqrt(E / sc.n_obs)), **info,
     }
     if config2:
@@ -313,6 +452,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
     ap.add_argument("--depth-rows", type=int, default=1_000_000, help="points of the projective-depth iteration leg (0 = skip)")
+    ap.add_argument("--no-config4-shard-leg", action="store_true",
+                    help="N=1 default run: skip the short leg on config 4's per-GPU shard (~6 s: scene 1.7 s, create 0.3 s, 4 LM iterations)")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N>1: rccl = one GPU per rank, ncclAllReduce inside libmvba (default); host = the reduced system is "
                          "staged through the host and summed over gloo, ranks may share a GPU (one-GPU rehearsal of the N>1 path)")
@@ -495,43 +636,12 @@ def main():
         # ~100 fp64 FMA per lane-step of 21 items x 3 lanes.
         ms_solve = dt / max(n_solves, 1) * 1e3
         info = eng.schur_info()
-        k3_bytes = 192 * sc.n_obs
-        k3_ach = k3_bytes / (k3_ms * 1e-3) / 1e9
-        k3_name = {"strip": "k_schur_strip", "pairs": "k_schur_pairs", "slots": "k_schur_slots"}[info["kernel"]]
-        k3_traffic, k3_src = pmc_traffic(k3_name, sc.n_obs)
-        gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
-        flops = info["items"] * 3 * 96 * 2
-        # what bounds K3.  Slot form: the rate at which a CU gathers rows out of its L2 into LDS -- every step
-        # row is three row gathers (k-side record; l-side record or, on a diagonal row, the residual slot; point row), padding
-        # rows included -- against the ceiling of the bare gather loop (tools/microbench/gather_lines.hip).  Unit form:
-        # the fabric (L2 misses at the HBM rate).
         n_cu = 256
         try:
             n_cu = int(torch.cuda.get_device_properties(device).multi_processor_count)
         except Exception:  # noqa: BLE001
             pass
-        gather_rows = 3 * (info["slot_rows"] or info["items"])
-        rows_rate = gather_rows / (k3_ms * 1e3) / n_cu
-        slot_form = info["kernel"] == "slots"
-        roof_k3 = {"kernel": k3_name + " (K3)",
-                   "bound": "l2_gather" if slot_form else "hbm",
-                   "bound_note": ("not HBM: the CU's L2 -> LDS row-gather pipe (see `gather`); `achieved` / `frac` price SURVEY 8d's algorithmic "
-                                  "192 B/observation against the HBM peak as the contract asks" if slot_form else
-                                  "fabric: the kernel's L2 misses run at the HBM rate (see `traffic`)"),
-                   "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,
-                   "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
-                   "algorithmic_bytes_per_launch": k3_bytes, "algorithmic_bytes_per_obs": 192, "avg_launch_ms": k3_ms,
-                   "items": info["items"], "units": info["units"],
-                   "slot_rows_incl_padding": info["slot_rows"] or None,
-                   "gather": {"row_gathers_per_launch": gather_rows, "rows_per_us_per_cu": rows_rate,
-                              "ceiling_rows_per_us_per_cu": GATHER_CEILING_ROWS_PER_US_PER_CU,
-                              "frac": rows_rate / GATHER_CEILING_ROWS_PER_US_PER_CU, "compute_units": n_cu,
-                              "definition": "3 row gathers per step row (padding rows included) / launch time / CUs; ceiling: "
-                                            "profiles/r03_microbench_gather_rows.txt (717-759 rows/us per CU from L2)"},
-                   "gathered_bytes_per_launch": gather, "gather_GBs": gather / (k3_ms * 1e-3) / 1e9,
-                   "fp64_tflops": flops / (k3_ms * 1e-3) / 1e12,
-                   "frac_of_fp64_valu_peak": flops / (k3_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+        roof_k3 = schur_roofline(info, sc.n_obs, k3_ms, n_cu)
         roof_k1 = {"kernel": "k_resid_jac (K1+K2)", "bound": "hbm", "achieved": k1_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": k1_ach / HBM_PEAK_GBS, "traffic": k1_traffic, "traffic_source": k1_src,
                    "traffic_unit": "bytes per launch (PMC, committed profile -- not measured in this run)",
@@ -571,6 +681,7 @@ def main():
             "allreduce": ({"ms_per_solve": st_table["allreduce"]["ms"] / max(table_solves, 1),
                            "bytes_per_solve": 8 * (81 * n_cams * (n_cams + 1) // 2 + 9 * n_cams), "ranks": world,
                            "transport": args.transport} if multi else None),
+            "allreduce_model": allreduce_model(n_cams, max(world, 2)) if (multi or config4 or shard4) else None,
             "resid_jac_gobs_per_s": n_obs_total / (k1_ms * 1e-3) / 1e9,
             "inner_solves": n_solves,
             "ms_per_inner_solve": ms_solve,
@@ -606,6 +717,12 @@ def main():
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
             if args.depth_rows > 0:
                 out["depth_iteration"] = depth_iteration(args.depth_rows)
+        if world == 1 and not args.no_config4_shard_leg and not (shard4 or config4 or args.points or args.cams or args.vis):
+            eng.close()  # (idempotent) the config-3 engine's ~4 GB go back before the shard's ~11 GB are taken
+            try:
+                out["config4_shard"] = config4_shard_leg(device)
+            except Exception as exc:  # noqa: BLE001
+                out["config4_shard"] = {"error": repr(exc)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
