@@ -2938,7 +2938,14 @@ void drain_events(mvba_handle *h) {  // call after a stream sync
 
 template <typename T>
 int dmalloc(T **p, size_t n) {
-  MVBA_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  const hipError_t e = hipMalloc((void **)p, bytes);
+  if (e != hipSuccess) {  // say how much was asked for and how much there is: "out of memory" alone does not tell a scene from a knob
+    size_t fr = 0, tot = 0;
+    hipMemGetInfo(&fr, &tot);
+    return fail(MVBA_ERR_HIP, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e) + " (" + std::to_string(fr >> 20) +
+                                  " MiB free of " + std::to_string(tot >> 20) + ")");
+  }
   return MVBA_OK;
 }
 
@@ -3763,6 +3770,18 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       for (long long b = 0; b < n_waves; ++b) w_beg[b + 1] = w_beg[b] + w_steps[b];
       const long long total_steps = w_beg[n_waves];
       if (total_steps * PSTEP >= (1LL << 40)) { mvba_destroy(h); return fail(MVBA_ERR_BADARG, "too many (point, camera pair) items"); }
+      {  // the step-major index -- its size follows the opt-in knobs (skew, window, groups: padding rows) -- against the memory that is
+        // there, BEFORE anything of it is allocated: three 4-byte arrays of step rows, then the interleaved 256-byte rows beside them
+        const size_t need = (size_t)total_steps * PSTEP * 12 + (size_t)total_steps * SLOT_IDX * 4 + seg_end.size() * 4;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > fr) {
+          mvba_destroy(h);
+          return fail(MVBA_ERR_BADARG, "the slot-form Schur index needs " + std::to_string(need >> 20) + " MiB (" + std::to_string(total_steps * PSTEP) + " step rows for " +
+                                           std::to_string(T) + " items: " + std::to_string(n_rounds) + " rounds x " + std::to_string(nR) + " ranges, skew " + std::to_string(skew) +
+                                           ", window " + std::to_string(h->slot_window) + (equalize ? " (equalised)" : "") + "), " + std::to_string(fr >> 20) +
+                                           " MiB of device memory are free: relax MVBA_SLOT_SKEW / MVBA_SLOT_WINDOW / MVBA_SLOT_GROUPS or use MVBA_SCHUR=pairs");
+        }
+      }
       if (dev_items) {  // the step-major arrays are written where the kernel will read them
         const size_t rows = (size_t)total_steps * PSTEP;
         TRY(dmalloc(&h->d_it_k, rows)); TRY(dmalloc(&h->d_it_l, rows)); TRY(dmalloc(&h->d_it_a, rows));

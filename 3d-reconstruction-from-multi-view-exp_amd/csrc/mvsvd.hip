@@ -1055,10 +1055,10 @@ __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, 
 // task 10 m <= t < 14 m: image, component i -> 3 column sums.  One thread per task, rows in order, no atomics.
 __constant__ int c_pair_i[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
 __constant__ int c_pair_j[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
-constexpr int DG_ROWS = 128;  // rows staged per pass of k_dual_gram
+constexpr int DG_ROWS_MAX = 128;  // rows staged per pass of k_dual_gram (fewer when 3 m columns of them do not fit the LDS: dual_gram_rows)
 template <typename T>
 __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
-                                                   double is3, long long n_rows, int m, long long rows_per_block,
+                                                   double is3, long long n_rows, int m, long long rows_per_block, int DG_ROWS,
                                                    double *__restrict__ part /*[blocks][14 m][6]*/) {
   // staged per pass: x^ [DG_ROWS][3m] (stride 3m | 1) and v4 [DG_ROWS][4]: the normalisation happens once per (row, image),
   // not once per task, and the tasks read LDS (rows broadcast within a wave: all its lanes are on the same row)
@@ -1411,6 +1411,9 @@ int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
 }
 
 constexpr int DEPTH_BLOCKS = 2048;  // blocks of the per-point passes / of the dual Gram pass
+constexpr size_t DEPTH_LDS_MAX = 148 * 1024;  // dynamic LDS the depth kernels may ask for (+ 2 KiB static in block_sum_to)
+// rows k_dual_gram stages per pass: [rows][3 m | 1] normalised observations + [rows][4] right singular vectors in LDS
+inline int dual_gram_rows(int m) { return (int)std::max<size_t>(1, std::min<size_t>(DG_ROWS_MAX, DEPTH_LDS_MAX / (sizeof(double) * (size_t)(((3 * m) | 1) + 4)))); }
 
 template <typename T>
 int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timings) {
@@ -1427,10 +1430,8 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
   const int gblocks = (int)((rows + rpb - 1) / rpb);
   const int dsplit = 14 * m <= 64 ? 4 : (14 * m <= 128 ? 2 : 1);  // thread groups of k_dual_gram, each with its own partial
   const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + (size_t)dual_blocks * dsplit * 14 * m * 6;
-  if (!h->ddep) {
-    MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));
-    MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
-  }
+  if (!h->ddep) MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));  // (m is the handle's: `need` never changes)
+  if (!h->ddflag) MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
   double *Epart = h->ddep, *Eout = Epart + DEPTH_BLOCKS, *G12 = Eout + 8, *V12 = G12 + (size_t)m * 144, *colsum = V12 + (size_t)m * 144,
          *w12 = colsum + (size_t)m * 12, *gpart = w12 + (size_t)m * 12;
   const int pgrid = (int)std::max<long long>(1, std::min<long long>(DEPTH_BLOCKS, (rows + 255) / 256));
@@ -1452,8 +1453,9 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
       is[i] = 1.0 / (double)sigma[i];
     }
     MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), sizeof(double) * ((size_t)DG_ROWS * ((n | 1) + 4)), st, (const T *)h->dX, (const T *)h->dS,
-                       is[0], is[1], is[2], is[3], rows, m, rpb, gpart);
+    const int dg_rows = dual_gram_rows(m);  // (128 up to 47 images, 24 at 256: the launch used to FAIL from 48 images on)
+    hipLaunchKernelGGL(k_dual_gram<T>, dim3(gblocks), dim3(256), sizeof(double) * ((size_t)dg_rows * ((n | 1) + 4)), st, (const T *)h->dX, (const T *)h->dS,
+                       is[0], is[1], is[2], is[3], rows, m, rpb, dg_rows, gpart);
     hipLaunchKernelGGL(k_dual_reduce, dim3((14 * m * 6 + 3) / 4), dim3(256), 0, st, gpart, gblocks * dsplit, m, G12, colsum);
     hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
     hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
@@ -1517,7 +1519,7 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   for (const void *f : {(const void *)k_scale_rows_tiled<float>, (const void *)k_scale_rows_tiled<double>, (const void *)k_depth_primary<float, true>,
                         (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
                         (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>})
-    SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));  // (+ 2 KiB static in block_sum_to)
+    SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX));
 #undef SVD_TRY
   *out = h;
   return MVBA_OK;
@@ -1586,7 +1588,7 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   if (ng > 256) return fail(MVBA_ERR_BADARG, "at most 256 column groups");
   MVBA_HIP(hipSetDevice(h->device));
   const size_t el = h->dtype ? 8 : 4;
-  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
+  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * h->n));  // (room for any grouping: a later call may ask for a finer one)
   hipEventRecord(h->ev[0], h->st);
   MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
   hipEventRecord(h->ev[1], h->st);
@@ -1609,7 +1611,7 @@ int mvsvd_depth_begin(mvsvd_handle *h, int32_t group) {
   MVBA_HIP(hipSetDevice(h->device));
   const size_t el = h->dtype ? 8 : 4;
   const int ng = h->n / 3;
-  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * ng));
+  if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * h->n));  // (shared with mvsvd_run_scaled, whose groups may be finer)
   const long long cnt = h->base_rows * ng;
   const int grid = (int)std::max<long long>(1, std::min<long long>(4096, (cnt + 255) / 256));
   if (h->dtype == 0) hipLaunchKernelGGL(k_fill<float>, dim3(grid), dim3(256), 0, h->st, (float *)h->dz, cnt, 1.0f);
@@ -1623,7 +1625,7 @@ int mvsvd_depth_step(mvsvd_handle *h, int32_t method, double f0, double *E, doub
   if (!h || !E) return fail(MVBA_ERR_BADARG, "null argument");
   if (!h->base_loaded || h->depth_group != 3) return fail(MVBA_ERR_STATE, "mvsvd_depth_step before mvsvd_depth_begin");
   if (method != 1 && method != 2) return fail(MVBA_ERR_BADARG, "method must be 1 (primary) or 2 (dual)");
-  if (h->n < 12) return fail(MVBA_ERR_BADARG, "the rank-4 depth iteration needs at least 4 images");
+  if (h->n < 6) return fail(MVBA_ERR_BADARG, "the rank-4 depth iteration needs at least 2 images (3 m >= 4 columns, as the reference's)");
   MVBA_HIP(hipSetDevice(h->device));
   return h->dtype == 0 ? depth_step<float>(h, method, f0, E, timings_ms) : depth_step<double>(h, method, f0, E, timings_ms);
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -405,12 +406,19 @@ class SvdWorkspace:
 
 
 _svd_cache = {}  # (dtype, n_cols, device) -> SvdWorkspace kept between public factorization calls
+_svd_cache_lock = threading.Lock()  # (ranks may be threads of one process: lib._distributed.InProcessGroup)
+_svd_cache_atexit = False
 
 
 def _svd_cache_clear():
-    for ws in _svd_cache.values():
-        ws.close()
-    _svd_cache.clear()
+    """Release the cached SVD workspaces (~2 GB of device memory at config 5); also registered at interpreter exit."""
+    with _svd_cache_lock:
+        for ws in _svd_cache.values():
+            ws.close()
+        _svd_cache.clear()
+
+
+svd_cache_clear = _svd_cache_clear  # public name: call it to hand the cached workspaces' device memory back (e.g. before a large BundleAdjuster)
 
 
 def svd_factorize(Wt, n_rank, center=False, device=-1):
@@ -428,17 +436,22 @@ def svd_factorize(Wt, n_rank, center=False, device=-1):
         Wt = Wt.astype(np.float64)
     n_rows, n_cols = Wt.shape
     if os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 2048:
+        global _svd_cache_atexit
         key = (Wt.dtype.str, n_cols, int(device))
-        ws = _svd_cache.get(key)
-        if ws is None or ws.max_rows < n_rows:
-            if ws is not None:
-                ws.close()
-            if not _svd_cache:
-                import atexit
+        with _svd_cache_lock:  # (held through the call: a workspace is one matrix and one stream)
+            ws = _svd_cache.get(key)
+            if ws is None or ws.max_rows < n_rows:
+                old = _svd_cache.pop(key, None)  # out of the cache BEFORE it is closed: a failing allocation below must not leave a closed handle behind
+                if old is not None:
+                    old.close()
+                if not _svd_cache_atexit:
+                    import atexit
 
-                atexit.register(_svd_cache_clear)
-            ws = _svd_cache[key] = SvdWorkspace(n_rows, n_cols, Wt.dtype, device)
-        return ws.load(Wt).run(n_rank, center)
+                    atexit.register(_svd_cache_clear)
+                    _svd_cache_atexit = True
+                ws = SvdWorkspace(n_rows, n_cols, Wt.dtype, device)
+                _svd_cache[key] = ws
+            return ws.load(Wt).run(n_rank, center)
     M = np.empty((n_cols, n_rank), Wt.dtype)
     sigma = np.empty(n_cols, Wt.dtype)
     S = np.empty((n_rank, n_rows), Wt.dtype)

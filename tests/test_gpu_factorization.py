@@ -319,6 +319,76 @@ def test_depth_iteration_on_the_device_equals_the_oracle_per_step(method):
     ws.close()
 
 
+@pytest.mark.parametrize("n_points,m,method", [(1500, 3, 1), (1500, 3, 2), (1500, 2, 1), (1200, 16, 1), (1200, 16, 2), (800, 64, 1), (800, 64, 2)])
+def test_depth_iteration_image_counts_vs_oracle(n_points, m, method):
+    """Image counts at the edges of the device depth loop's kernel variants, against oracle/depth_oracle.py per step (1e-9): two and
+    three views (the reference's loops only need 3 m >= 4 columns; the device loop refused fewer than four until round 5), 16 images
+    in fp64 (the rows no longer fit the LDS tiles: the per-lane variants of k_depth_primary / k_dual_apply, which no test ran before),
+    64 images (k_dual_gram stages fewer than 128 rows per pass there -- its launch used to fail from 48 images on -- and walks its
+    14 m = 896 tasks in more than one batch per thread)."""
+    from lib.perspective_camera_calibration import _create_data_matrix
+    from lib.synthetic import make_scene
+    from oracle.depth_oracle import HostDepthLoop
+
+    sc = make_scene(n_points, m, vis_p=1.0)
+    xd, _vis = sc.dense()
+    x = _create_data_matrix([xd[:, k, :] for k in range(m)], 1.0)
+    g = HostDepthLoop(x)
+    ws = _mvba.SvdWorkspace(n_points, 3 * m, np.float64)
+    ws.load_base(x.reshape(n_points, 3 * m))
+    ws.depth_begin(3)
+    for _ in range(3):
+        E, _tm = ws.depth_step(method, 1.0)
+        Eo = g.step(method, 1.0)
+        assert E == pytest.approx(Eo, rel=1e-9, abs=1e-14)
+        np.testing.assert_allclose(ws.depth_read(), g.depths(), rtol=0, atol=1e-9)
+    ws.close()
+
+
+def test_a_coarser_grouping_after_a_finer_one_fits_the_depth_buffer():
+    """mvsvd_run_scaled with one depth per COLUMN after the depth loop (one per image) on the same handle, and back: the depth buffer
+    is sized for the finest grouping from its first allocation (it used to keep the size of whichever caller came first)."""
+    rng = np.random.default_rng(5)
+    n, cols = 4000, 12
+    X = rng.standard_normal((n, cols))
+    ws = _mvba.SvdWorkspace(n, cols, np.float64)
+    ws.load_base(X)
+    ws.depth_begin(3)
+    ws.depth_step(1, 1.0)
+    z1 = rng.uniform(0.5, 1.5, (n, cols))
+    M, sig, S, _ = ws.run_scaled(z1, 1, 0, 4)[:4]
+    ref = np.linalg.svd((X * z1).T, full_matrices=False)[1]
+    np.testing.assert_allclose(sig[:4], ref[:4], rtol=1e-10)
+    z6 = rng.uniform(0.5, 1.5, (n, 2))
+    sig6 = ws.run_scaled(z6, 6, 0, 4)[1]
+    np.testing.assert_allclose(sig6[:4], np.linalg.svd((X * np.repeat(z6, 6, axis=1)).T, full_matrices=False)[1][:4], rtol=1e-10)
+    ws.close()
+
+
+def test_a_failed_regrow_does_not_leave_a_closed_workspace_in_the_cache(monkeypatch):
+    """svd_factorize keeps one workspace per (dtype, columns, device) and grows it for a larger matrix: if that allocation fails the
+    cache must not keep the CLOSED old workspace (every later, smaller call would then pass a null handle)."""
+    rng = np.random.default_rng(2)
+    _mvba.svd_cache_clear()
+    small = rng.standard_normal((500, 9))
+    _mvba.svd_factorize(small, 3)
+    real = _mvba.SvdWorkspace
+
+    class Boom(RuntimeError):
+        pass
+
+    def failing(*a, **k):
+        raise Boom("out of memory (simulated)")
+
+    monkeypatch.setattr(_mvba, "SvdWorkspace", failing)
+    with pytest.raises(Boom):
+        _mvba.svd_factorize(rng.standard_normal((900, 9)), 3)
+    monkeypatch.setattr(_mvba, "SvdWorkspace", real)
+    M, sig = _mvba.svd_factorize(small, 3)[:2]
+    np.testing.assert_allclose(sig[:3], np.linalg.svd(small.T, full_matrices=False)[1][:3], rtol=1e-10)
+    _mvba.svd_cache_clear()
+
+
 def test_depth_iteration_in_float32():
     """The same iteration on a float32 workspace: depths good to float32."""
     from lib.perspective_camera_calibration import _create_data_matrix

@@ -3,12 +3,12 @@
 # bench line (Schur ms per solve, step rows / items) and, with PMC=1 in a group, the L2 hit / miss counts of the kernel
 # usage: tools/sweep_c4.sh "VAR=a VAR2=b" "VAR=c PMC=1" ...   (one quoted group of assignments per run)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-ARGS="--points 1250000 --cams 500 --vis 0.05 --steps 4 --warmup 1 --no-cpu-baseline --svd-rows 0"
+ARGS="--points 1250000 --cams 500 --vis 0.05 --steps 4 --warmup 1 --no-cpu-baseline --svd-rows 0 --depth-rows 0"
 i=0
 for grp in "$@"; do
   i=$((i+1))
   ( for kv in $grp; do export "$kv"; done
-    timeout -k 10 300 python bench.py $ARGS > gpurun_out/swc_$i.json 2> gpurun_out/swc_$i.err || { tail -3 gpurun_out/swc_$i.err; exit 0; }
+    timeout -k 10 300 python bench.py $ARGS > gpurun_out/swc_$i.json 2> gpurun_out/swc_$i.err || { echo "$grp | FAILED:"; tail -2 gpurun_out/swc_$i.err; exit 0; }
     python -c "
 import json; d=json.load(open('gpurun_out/swc_$i.json')); r=d['roofline_schur']; print('$grp', '|', r['kernel'], 'schur', round(d['kernel_ms_per_step']['schur']/max(d['inner_solves'],1)*d['steps'],3), 'ms/solve  step', round(d['ms_per_step'],2), 'rows/items', round((r['slot_rows_incl_padding'] or 0)/r['items'],3), 'create_s', round(d['config']['engine_create_s'],2))"
     if [ -n "$PMC" ]; then
