@@ -162,7 +162,12 @@ __device__ __forceinline__ const T MVBA_CONST_AS *as_const(const T *p) {
 // observations -- PL[a][9] = Exx,Exy,Exz,Eyy,Eyz,Ezz,dP0..2 -- so the records are not re-read.
 // Algorithmic traffic: 24 B in + 128 B out per observation + (24 in + 72 out) B per point.
 constexpr int REC = 8;  // double2 slots per observation record (128 B)
+constexpr int LDS_CAMERAS = 646;  // cameras whose tables (K1: 18 doubles + the waves' staging tiles; K5: 28 doubles) fit one workgroup's LDS
 
+// GCAM: beyond LDS_CAMERAS cameras the expanded camera table does not fit a workgroup's LDS next to its staging tiles; the
+// kernels then read the rows of a table in device memory (k_cam_tables; 144 bytes per camera, L2-resident) through the same
+// 16-byte loads.  One template parameter per kernel: the LDS form keeps its ds_read_b128, nothing is decided per access.
+template <bool GCAM>
 __global__ __launch_bounds__(1024, 4) void k_resid_jac(long long nobs, int m, const double *__restrict__ cam15,
                                                    const double *__restrict__ X,
                                                    const int *__restrict__ obs_pt,
@@ -170,19 +175,22 @@ __global__ __launch_bounds__(1024, 4) void k_resid_jac(long long nobs, int m, co
                                                    const double2 *__restrict__ xy, double f0,
                                                    const int *__restrict__ tile_start, int n_tiles,
                                                    double2 *__restrict__ rec, double *__restrict__ PL,
-                                                   const int *__restrict__ tile_slot, double *__restrict__ PLsplit) {
+                                                   const int *__restrict__ tile_slot, double *__restrict__ PLsplit,
+                                                   const double *__restrict__ gcam) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *s_cam = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   // per-wave 8 KiB staging tile, 16-byte aligned behind the camera table
-  double2 *stage = reinterpret_cast<double2 *>(smem + ((m * CAM_LDS + 1) & ~1)) + wave * (64 * REC);
+  double2 *stage = reinterpret_cast<double2 *>(smem + (GCAM ? 0 : ((m * CAM_LDS + 1) & ~1))) + wave * (64 * REC);
   // the same 8 KiB is reused for the per-point sums: contrib[9][CS] doubles (odd stride: the nine
   // components of one observation sit in nine different banks), then seg_start[65], pt[64]
   constexpr int CS = 65;
   double *contrib = reinterpret_cast<double *>(stage);
   int *seg_start = reinterpret_cast<int *>(contrib + 9 * CS), *seg_pt = seg_start + 66;
-  load_cams_to_lds(cam15, m, f0, s_cam);
-  __syncthreads();
+  if (!GCAM) {
+    load_cams_to_lds(cam15, m, f0, s_cam);
+    __syncthreads();
+  }
   // Wave tiles are POINT-ALIGNED (built once on the host): whole points packed greedily into at
   // most 64 observations, so every per-point sum below is complete inside one wave -> plain
   // stores, no atomics, bitwise-reproducible E_a / dP_a.  Only a point with more than 64
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(1024, 4) void k_resid_jac(long long nobs, int m, co
       const double2 z = xy[o];
       const double *Xa = X + 3 * (size_t)a;
       ObsJ J;
-      obs_math(Xa[0], Xa[1], Xa[2], s_cam + k * CAM_LDS, z.x, z.y, f0, J);
+      obs_math(Xa[0], Xa[1], Xa[2], GCAM ? gcam + (size_t)k * CAM_LDS : s_cam + k * CAM_LDS, z.x, z.y, f0, J);
       // swizzled slot position (s ^ (lane & 7)): conflict-free ds_write_b128
       double2 *row = stage + lane * REC;
       const int sw = lane & 7;
@@ -2420,14 +2428,15 @@ __global__ void k_update_cams(int m, const double *__restrict__ cam15, const dou
 // The trial cost is k_cost on the trial state (K6).
 // BT threads per block: 256, or 1024 once the camera tables (m x 28 doubles) leave room for one block per CU only
 // (beyond ~230 cameras: four waves per CU then; config 4's shard 0.47 -> see profiles/r04_m_*)
-template <int G, int BT = 256>
+template <int G, int BT = 256, bool GCAM = false>
 __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const long long *__restrict__ pt_ptr,
                                                  const int *__restrict__ cam_idx, const double *__restrict__ PB,
                                                  const double *__restrict__ dxi, const double *__restrict__ X,
                                                  const double *__restrict__ cam15, double f0, double *__restrict__ Xt,
-                                                 double *__restrict__ dX) {
+                                                 double *__restrict__ dX, const double *__restrict__ gcam, const double *__restrict__ gdxi) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *s_dxi = smem, *s_cam = smem + DXI_LDS * m;
+  if (!GCAM) {
   for (int i0 = threadIdx.x; i0 < 9 * m; i0 += 4 * blockDim.x) {  // (loads in batches of four: see k_point_inv)
     double t[4];
 #pragma unroll
@@ -2440,6 +2449,7 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
   }
   load_cams_to_lds(cam15, m, f0, s_cam);
   __syncthreads();
+  }
   // G lanes per point (template).  Measured with 2 / 4 / 8 lanes: config 3 (10 observations per point)
   // 0.198 / 0.207 / 0.235 ms, config-4 shard (25 per point) 0.783 / 0.816 / 0.873 ms; one lane: 0.208
   const int s = threadIdx.x & (G - 1), grp = threadIdx.x / G;
@@ -2465,7 +2475,7 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
     for (int u = 0; u < PF; ++u)
       if (o0 + s + G * u < o1) {
         double t0, t1, t2;
-        obs_backsub(Xa0, Xa1, Xa2, s_cam + kk[u] * CAM_LDS, s_dxi + DXI_LDS * kk[u], f0, t0, t1, t2);
+        obs_backsub(Xa0, Xa1, Xa2, GCAM ? gcam + (size_t)kk[u] * CAM_LDS : s_cam + kk[u] * CAM_LDS, GCAM ? gdxi + (size_t)DXI_LDS * kk[u] : s_dxi + DXI_LDS * kk[u], f0, t0, t1, t2);
         y0 += t0;
         y1 += t1;
         y2 += t2;
@@ -2473,7 +2483,7 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
     for (long long o = o0 + s + G * PF; o < o1; o += G) {
       const int k = cam_idx[o];
       double t0, t1, t2;
-      obs_backsub(Xa0, Xa1, Xa2, s_cam + k * CAM_LDS, s_dxi + DXI_LDS * k, f0, t0, t1, t2);
+      obs_backsub(Xa0, Xa1, Xa2, GCAM ? gcam + (size_t)k * CAM_LDS : s_cam + k * CAM_LDS, GCAM ? gdxi + (size_t)DXI_LDS * k : s_dxi + DXI_LDS * k, f0, t0, t1, t2);
       y0 += t0;
       y1 += t1;
       y2 += t2;
@@ -2494,15 +2504,30 @@ __global__ __launch_bounds__(BT) void k_backsub(long long npts, int m, const lon
   }
 }
 
+// Beyond LDS_CAMERAS: the expanded camera rows (and, for the back-substitution, the padded update rows) in device memory
+__global__ void k_cam_tables(int m, const double *__restrict__ cam15, const double *__restrict__ dxi, double f0, double *__restrict__ cam18,
+                             double *__restrict__ dxi10) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  expand_cam(cam15 + (size_t)k * CAM_IN, f0, cam18 + (size_t)k * CAM_LDS);
+  if (dxi) {
+    for (int i = 0; i < 9; ++i) dxi10[(size_t)k * DXI_LDS + i] = dxi[9 * (size_t)k + i];
+    dxi10[(size_t)k * DXI_LDS + 9] = 0.0;
+  }
+}
+
 // residual-only pass at a given state (initial cost, ref :85-87)
+template <bool GCAM>
 __global__ __launch_bounds__(512) void k_cost(long long nobs, int m, const double *__restrict__ cam15,
                                               const double *__restrict__ X, const int *__restrict__ obs_pt,
                                               const int *__restrict__ cam_idx, const double2 *__restrict__ xy,
-                                              double f0, double *__restrict__ partials) {
+                                              double f0, double *__restrict__ partials, const double *__restrict__ gcam) {
   extern __shared__ __attribute__((aligned(16))) double s_cam[];
   __shared__ double s_red[16];
-  load_cams_to_lds(cam15, m, f0, s_cam);
-  __syncthreads();
+  if (!GCAM) {
+    load_cams_to_lds(cam15, m, f0, s_cam);
+    __syncthreads();
+  }
   double cost = 0.0;
   const long long stride = (long long)gridDim.x * blockDim.x;
   // two dependent memory latencies per observation (its indices, then its point): the next
@@ -2519,7 +2544,7 @@ __global__ __launch_bounds__(512) void k_cost(long long nobs, int m, const doubl
     a_n = obs_pt[on];
     k_n = cam_idx[on];
     z_n = xy[on];
-    cost += obs_cost(X0, X1, X2, s_cam + k * CAM_LDS, z.x, z.y, f0);
+    cost += obs_cost(X0, X1, X2, GCAM ? gcam + (size_t)k * CAM_LDS : s_cam + k * CAM_LDS, z.x, z.y, f0);
   }
   const double t = block_sum(cost, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -2839,6 +2864,8 @@ struct mvba_handle {
   bool slot_pace = true;
   int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
   int *d_seg_end = nullptr, *d_prog = nullptr;
+  bool gcam = false;                  // more than LDS_CAMERAS cameras: the kernels read the camera tables from device memory (d_cam18, d_dxi10)
+  double *d_cam18 = nullptr, *d_dxi10 = nullptr;
   bool index_on_device = false;       // the Schur index was built by the k_idx_* kernels (nothing to upload)
   long long *d_trace = nullptr;       // -DMVBA_SLOT_TRACE builds with MVBA_SLOT_TRACE=<file>: per-wave timings of the last launch
   int4 *d_wdesc = nullptr;
@@ -3035,12 +3062,20 @@ int global_cost(mvba_handle *h, double *E) {
   return MVBA_OK;
 }
 
+// the camera tables in device memory for the kernels that cannot hold them in LDS (no-op up to LDS_CAMERAS cameras)
+void cam_tables(mvba_handle *h, const double *cam15, const double *dxi) {
+  if (h->gcam) hipLaunchKernelGGL(k_cam_tables, dim3((h->m + 255) / 256), dim3(256), 0, h->stream, h->m, cam15, dxi, h->f0, h->d_cam18, h->d_dxi10);
+}
+void launch_cost_kernel(mvba_handle *h, const double *cam15, const double *X) {
+  const size_t lds = h->gcam ? 0 : (size_t)h->m * CAM_LDS * sizeof(double);
+  cam_tables(h, cam15, nullptr);
+  // (512 threads once the camera table leaves room for two blocks per CU only: config 4's 500 cameras)
+  hipLaunchKernelGGL(h->gcam ? k_cost<true> : k_cost<false>, dim3(h->cost_grid), dim3(lds > 40 * 1024 ? 512 : 256), lds, h->stream, h->nobs, h->m, cam15, X,
+                     h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials, h->d_cam18);
+}
 int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   Timed t(h, MVBA_K_COST);
-  const size_t lds = (size_t)h->m * CAM_LDS * sizeof(double);
-  // (512 threads once the camera table leaves room for two blocks per CU only: config 4's 500 cameras)
-  hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(lds > 40 * 1024 ? 512 : 256), lds, h->stream, h->nobs, h->m, cam15, X, h->d_obs_pt,
-                     h->d_cam, h->d_xy, h->f0, h->d_partials);
+  launch_cost_kernel(h, cam15, X);
   double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
   const unsigned long long seq = h->cost_seq;
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, mail, seq);
@@ -3081,12 +3116,14 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   // the kernels keep the whole camera table in LDS (K1: 18 doubles per camera + 8 x 8 KiB of wave
   // tiles; back-substitution: 28 per camera): 160 KiB per workgroup caps the camera count.  (The documented limit is
   // round 1's, from 19 doubles per camera; 18 would admit 682.)
-  constexpr int MAX_CAMERAS = 646;
-  static_assert(MAX_CAMERAS * CAM_LDS + 8 * 64 * 2 * 8 + 2 <= 160 * 1024 / 8 && MAX_CAMERAS * (CAM_LDS + DXI_LDS) <= 160 * 1024 / 8,
-                "the camera tables of MAX_CAMERAS cameras fit one workgroup's LDS");
+  static_assert(LDS_CAMERAS * CAM_LDS + 8 * 64 * 2 * 8 + 2 <= 160 * 1024 / 8 && LDS_CAMERAS * (CAM_LDS + DXI_LDS) <= 160 * 1024 / 8,
+                "the camera tables of LDS_CAMERAS cameras fit one workgroup's LDS");
+  // (beyond LDS_CAMERAS the same kernels read the tables from device memory -- round 5; what caps the count now is the dense
+  // reduced system: D = 9 m - 7 = 36,857 at 4096 cameras is 10.9 GB of matrix, and the unit descriptors keep camera ids in 16 bits)
+  constexpr int MAX_CAMERAS = 4096;
   if (p->n_images > MAX_CAMERAS)
     return fail(MVBA_ERR_BADARG, "n_images = " + std::to_string(p->n_images) + " exceeds the " + std::to_string(MAX_CAMERAS) +
-                                     " cameras whose parameter table fits the 160 KiB of LDS of one workgroup");
+                                     " cameras this build solves a dense reduced system for");
   if (p->pt_ptr[0] != 0 || p->pt_ptr[p->n_points] != p->n_obs) return fail(MVBA_ERR_BADARG, "pt_ptr does not span n_obs");
   if (p->n_obs >= (1LL << 31) || p->n_points >= (1LL << 31))
     return fail(MVBA_ERR_BADARG, "n_obs and n_points per handle must be < 2^31");
@@ -3169,6 +3206,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (e != hipSuccess) { delete h; return fail(MVBA_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e)); }
   }
   h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7; h->ld = (h->D + 3) & ~3;
+  h->gcam = m > LDS_CAMERAS;
 #define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
   // the topology goes up first: the Schur index is built from it on the device
@@ -3190,7 +3228,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     // of 8 waves fill a CU (16 waves: the register limit); beyond that ONE block fits and its size decides the occupancy --
     // the smallest block that reaches the most waves per CU (200 cameras: 16 waves, 0.96 -> 0.70 ms at 1 M points x 10 %;
     // 300: 14, 0.41 -> 0.32-0.37; 500: 11, config 4's shard 1.53-1.58 -> 1.32-1.36; tools/sweep_k1.sh)
-    const size_t table = (size_t)((m * CAM_LDS + 1) & ~1) * sizeof(double), per_wave = 64 * 2 * REC * sizeof(double);
+    const size_t table = h->gcam ? 0 : (size_t)((m * CAM_LDS + 1) & ~1) * sizeof(double), per_wave = 64 * 2 * REC * sizeof(double);
     int best_w = 8, best_tot = 0;
     for (int w = 8; w <= 16; ++w) {
       const size_t per = table + w * per_wave;
@@ -3967,7 +4005,8 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
-  const int cam_lds = (int)((size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double));
+  const int cam_lds = h->gcam ? 0 : (int)((size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double));
+  if (h->gcam) { TRY(dmalloc(&h->d_cam18, (size_t)m * CAM_LDS)); TRY(dmalloc(&h->d_dxi10, (size_t)m * DXI_LDS)); }
   for (const void *f : {(const void *)k_backsub<2>, (const void *)k_backsub<4>, (const void *)k_backsub<8>, (const void *)k_backsub<2, 512>,
                         (const void *)k_backsub<4, 512>, (const void *)k_backsub<8, 512>, (const void *)k_backsub<2, 1024>,
                         (const void *)k_backsub<4, 1024>, (const void *)k_backsub<8, 1024>})
@@ -3985,9 +4024,9 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (const char *ev = getenv("MVBA_TRAIL64_MIN")) h->trail64_min = std::max(0, atoi(ev));
     if (const char *ev = getenv("MVBA_CHOL_BARRIER_POLLS")) h->barrier_polls = (unsigned)std::max(0LL, atoll(ev));
   }
-  TRYH(hipFuncSetAttribute((const void *)k_resid_jac, hipFuncAttributeMaxDynamicSharedMemorySize,
-                           (int)((size_t)(((m * CAM_LDS + 1) & ~1) + (h->k1_threads / 64) * 64 * 2 * REC) * sizeof(double))));
-  TRYH(hipFuncSetAttribute((const void *)k_cost, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
+  TRYH(hipFuncSetAttribute(h->gcam ? (const void *)k_resid_jac<true> : (const void *)k_resid_jac<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)((size_t)((h->gcam ? 0 : ((m * CAM_LDS + 1) & ~1)) + (h->k1_threads / 64) * 64 * 2 * REC) * sizeof(double))));
+  TRYH(hipFuncSetAttribute((const void *)k_cost<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cam_lds));
 #undef TRY
 #undef TRYH
   lap("device allocations + uploads");
@@ -4019,7 +4058,7 @@ void mvba_destroy(mvba_handle *h) {
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
                   h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
-                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0, h->d_it_x};
+                  h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0, h->d_it_x, h->d_cam18, h->d_dxi10};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
   if (h->h_cost) hipHostFree(h->h_cost);
@@ -4102,12 +4141,13 @@ int mvba_linearize(mvba_handle *h) {
   if (h->nobs) {
     Timed t(h, MVBA_K_RESID_JAC);  // K1 with K2 (per-point blocks) fused in
     const int kt = h->k1_threads;  // 8 waves share one camera table: 2 blocks = 16 waves per CU
-    const size_t lds = (size_t)(((h->m * CAM_LDS + 1) & ~1) + (kt / 64) * 64 * 2 * REC) * sizeof(double);
+    const size_t lds = (size_t)((h->gcam ? 0 : ((h->m * CAM_LDS + 1) & ~1)) + (kt / 64) * 64 * 2 * REC) * sizeof(double);
+    cam_tables(h, h->d_cam15[h->cur], nullptr);
     const int wpb = kt / 64;
     const int grid = std::max(1, std::min(2048 * 256 / kt, (h->n_tiles + wpb - 1) / wpb));
-    hipLaunchKernelGGL(k_resid_jac, dim3(grid), dim3(kt), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
+    hipLaunchKernelGGL(h->gcam ? k_resid_jac<true> : k_resid_jac<false>, dim3(grid), dim3(kt), lds, h->stream, h->nobs, h->m, h->d_cam15[h->cur],
                        h->d_X[h->cur], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_tiles, h->n_tiles, h->d_rec, h->d_PL,
-                       h->d_tile_slot, h->d_PLsplit);
+                       h->d_tile_slot, h->d_PLsplit, h->d_cam18);
     if (h->n_splits)
       hipLaunchKernelGGL(k_sum_split, dim3((9 * h->n_splits + 255) / 256), dim3(256), 0, h->stream, h->n_splits, h->d_splits,
                          h->d_PLsplit, h->d_PL);
@@ -4222,7 +4262,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     hipLaunchKernelGGL(k_update_cams, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_cam15[h->cur], h->d_dxi,
                        h->d_cam15[trial]);
     if (h->N) {
-      const size_t lds = (size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double);
+      const size_t lds = h->gcam ? 0 : (size_t)m * (CAM_LDS + DXI_LDS) * sizeof(double);
+      cam_tables(h, h->d_cam15[h->cur], h->d_dxi);
       const int lanes_env = h->backsub_lanes;  // (MVBA_BACKSUB_LANES at create; 0 = by mean degree)
       const double deg = (double)h->nobs / (double)h->N;
       const int G = lanes_env ? lanes_env : (deg <= 40.0 ? 2 : (deg <= 100.0 ? 4 : 8));
@@ -4232,16 +4273,15 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
       const bool wide = lds > 80 * 1024, mid = !wide && lds > 40 * 1024;
       const int bt = wide ? 1024 : (mid ? 512 : 256);
       const int nblk = (int)std::min<long long>(4096 * 256 / bt, (h->N * G + bt - 1) / bt);
-      auto kern = wide ? (G == 2 ? k_backsub<2, 1024> : (G == 4 ? k_backsub<4, 1024> : k_backsub<8, 1024>))
+      auto kern = h->gcam ? (G == 2 ? k_backsub<2, 256, true> : (G == 4 ? k_backsub<4, 256, true> : k_backsub<8, 256, true>))
+                  : wide ? (G == 2 ? k_backsub<2, 1024> : (G == 4 ? k_backsub<4, 1024> : k_backsub<8, 1024>))
                   : mid ? (G == 2 ? k_backsub<2, 512> : (G == 4 ? k_backsub<4, 512> : k_backsub<8, 512>))
                         : (G == 2 ? k_backsub<2> : (G == 4 ? k_backsub<4> : k_backsub<8>));
       hipLaunchKernelGGL(kern, dim3(nblk), dim3(bt), lds, h->stream, h->N, m, h->d_pt_ptr, h->d_cam, h->d_PB, h->d_dxi,
-                         h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX);
+                         h->d_X[h->cur], h->d_cam15[h->cur], h->f0, h->d_X[trial], h->d_dX, h->d_cam18, h->d_dxi10);
     }
     // K6: trial cost = the residual-only pass at the trial state (fixed grid, fixed tree: deterministic)
-    const size_t clds = (size_t)h->m * CAM_LDS * sizeof(double);
-    hipLaunchKernelGGL(k_cost, dim3(h->cost_grid), dim3(clds > 40 * 1024 ? 512 : 256), clds, h->stream, h->nobs, h->m, h->d_cam15[trial],
-                       h->d_X[trial], h->d_obs_pt, h->d_cam, h->d_xy, h->f0, h->d_partials);
+    launch_cost_kernel(h, h->d_cam15[trial], h->d_X[trial]);
     double *mail = cost_mail(h);  // (advances cost_seq: sequenced before the launch reads it)
     const unsigned long long seq = h->cost_seq;
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, h->stream, h->d_partials, h->cost_grid, h->d_cost, h->d_flag, mail, seq);

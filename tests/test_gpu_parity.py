@@ -298,8 +298,8 @@ def test_error_behaviour_on_gpu(golden):
         eng.try_step(1e-4)  # before linearize
     with pytest.raises(ValueError):
         _mvba.HipEngine(3, 2, [0, 2, 4, 6], [0, 1, 1, 0, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
-    with pytest.raises(ValueError, match="646 cameras"):  # LDS camera-table ceiling is a stated limit, not a HIP error
-        _mvba.HipEngine(3, 647, [0, 2, 4, 6], [0, 1, 0, 1, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
+    with pytest.raises(ValueError, match="4096 cameras"):  # the ceiling is a stated limit, not a HIP error
+        _mvba.HipEngine(3, 4097, [0, 2, 4, 6], [0, 1, 0, 1, 0, 1], np.zeros((6, 2)), 1.0, "x-up_z-forward")
 
 
 def test_device_way_back_to_the_input_frame_matches_the_host_formula():
@@ -373,10 +373,12 @@ def test_virtual_point_shards_sum_to_the_full_reduced_system():
     assert withc.cost() == pytest.approx(full.cost(), rel=1e-13)
 
 
-@pytest.mark.parametrize("n,m,p", [(40, 2, 1.0), (900, 300, 0.06), (3000, 646, 0.04)])  # 646 = the largest count the LDS camera tables allow
+@pytest.mark.parametrize("n,m,p", [(40, 2, 1.0), (900, 300, 0.06), (3000, 646, 0.04), (3000, 647, 0.04), (2500, 1000, 0.03)])
 def test_extreme_camera_counts_vs_oracle(n, m, p):
-    """m = 2 (smallest legal gauge: D = 11) and m = 300 (the LDS strip of one camera no longer
-    fits and is cut into column segments, the path BASELINE config 4 with m = 500 takes)."""
+    """m = 2 (smallest legal gauge: D = 11), m = 300 (the LDS strip of one camera no longer fits and is cut into column
+    segments, the path BASELINE config 4 with m = 500 takes), m = 646 (the largest count whose camera tables fit one
+    workgroup's LDS) and, since round 5, beyond it: 647 and 1000 cameras (K1 / K5 / K6 read the tables from device memory;
+    the reference takes any count, ref :11-75)."""
     sc = make_scene(n, m, vis_p=p)
     ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K,
                                           sc.init_R, sc.init_t, axis=sc.axis)
