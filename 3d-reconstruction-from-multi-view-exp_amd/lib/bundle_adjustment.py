@@ -27,7 +27,10 @@ def dense_to_observations(x: npt.NDArray, visibility_index: npt.NDArray | None):
     """Dense ``x (N,m,2)`` + bool mask (ref :37, :56-60) -> CSR-by-point list.
     Invisible entries are dropped instead of multiplied by 0."""
     n, m = x.shape[:2]
-    vis = np.ones((n, m), dtype=np.bool_) if visibility_index is None else np.asarray(visibility_index, dtype=np.bool_)
+    if visibility_index is None:  # everything visible: the list is the array itself (np.nonzero + a gather took 0.24 s at 1 M x 12)
+        return (np.arange(n + 1, dtype=np.int64) * m, np.tile(np.arange(m, dtype=np.int32), n),
+                np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(n * m, 2)))
+    vis = np.asarray(visibility_index, dtype=np.bool_)
     pt, cam = np.nonzero(vis)
     pt_ptr = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(vis.sum(axis=1), out=pt_ptr[1:])

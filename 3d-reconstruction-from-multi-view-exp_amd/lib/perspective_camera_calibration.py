@@ -56,8 +56,11 @@ class _DeviceDepthLoop:
 
 def _create_data_matrix(x_list: list[npt.NDArray], f0: float) -> npt.NDArray:
     """(N, m, 3) homogeneous observations (x/f0, y/f0, 1)  (:34-40)."""
-    x = np.stack([np.column_stack([xi / f0, np.ones(len(xi))]) for xi in x_list])
-    return x.transpose(1, 0, 2)
+    x = np.empty((len(x_list[0]), len(x_list), 3))  # filled in place, contiguous: the stack + column_stack + transposed view of
+    for k, xi in enumerate(x_list):                 # the reference's form cost 0.08 s at 1 M points x 12 images, and a copy later
+        x[:, k, :2] = np.asarray(xi) / f0
+    x[:, :, 2] = 1.0
+    return x
 
 
 def _depth_iterations(x, f0, tolerance, max_iter, method, loop):

@@ -147,6 +147,62 @@ def test_euclidean_driver_reproduces_the_reference_run(golden, capsys):
     assert _rmse(x_list, X, K / K[:, 2:3, 2:3], R, t) < 0.01
 
 
+def test_euclidean_driver_start_of_ba_is_pinned_through_the_oracle_depth_loop(golden, capsys, monkeypatch):
+    """The tight check the device path cannot hold (see above), through a path that can: the same driver with the NumPy depth loop
+    of oracle/depth_oracle.py in place of the device loop starts BA at the reference's E0 to 1e-5 (everything else -- GPU SVD,
+    Euclidean upgrade, BA on the HIP engine -- unchanged); and the device loop itself is pinned where it is well conditioned: its
+    depths after the driver's whole depth loop (dual scheme, tol 1e-2) equal the oracle's to 1e-10."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-reconstruction-from-multi-view-exp_amd")
+    sys.path.insert(0, pkg)
+    import euclidiean_reconstruction as drv
+    import lib.perspective_camera_calibration as P
+    from oracle.depth_oracle import HostDepthLoop
+
+    d = golden("euclid_default")
+    x_list = [d["x"][:, k, :] for k in range(d["x"].shape[1])]
+    x = P._create_data_matrix(x_list, 1.0)
+    z_dev = P._compute_projective_depth_dual_method(x, 1.0, 1e-2)
+    z_host = P._compute_projective_depth_dual_method(x, 1.0, 1e-2, loop=HostDepthLoop(x))
+    np.testing.assert_allclose(z_dev, z_host, rtol=0, atol=1e-10)
+    monkeypatch.setattr(P, "_DeviceDepthLoop", HostDepthLoop)
+    _x, (X, K, R, t), log = drv.main(show=False)
+    capsys.readouterr()
+    E = np.array([e["reprojection_error"] for e in log])
+    assert abs(E[0] - d["E_log"][0]) < 1e-5 * d["E_log"][0], (E[0], d["E_log"][0])
+    assert abs(np.sqrt(E[-1] / 2000) - np.sqrt(d["E_log"][-1] / 2000)) < 1e-9
+
+
+def test_euclidean_pipeline_end_to_end_at_a_million_points():
+    """The reference's Euclidean pipeline (euclidiean_reconstruction.py:36-57) through the public surfaces at 1,000,000 points x 12
+    images, full visibility: synthetic observations -> perspective_self_calibration(x_list, 1.0, tol=1e-2, "dual") ->
+    BundleAdjuster(np.stack(x_list).transpose(1, 0, 2), ...).optimize(2.0, 1e-8, max_iter=30)  (tools/time_pipeline.py, which also
+    times every stage).  Too large for the oracle in a test, so properties: everything finite, the self-calibrated start already
+    reprojects to a few pixels' worth (1e-2 in normalised units), BA brings the reprojection RMSE -- evaluated independently through
+    calc_projected_points_gpu -- to the noise floor, and no host stage of the library swallows the run."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import time_pipeline
+
+    res = time_pipeline.run(1_000_000, 12, max_iter=30, tol=1e-2, noise=1e-3)
+    _timing_line("pipeline 1M x 12 (full visibility): " + ", ".join(f"{k} {v:.3f} s" for k, v in res["stages_s"].items())
+                 + f"; wall {res['pipeline_wall_s']:.3f} s, depth iterations {res['depth_iterations']}, LM iterations {res['lm_iterations']}")
+    assert res["finite"] and res["depth_iterations"] >= 1 and res["lm_iterations"] >= 5
+    assert res["rmse_after_self_calibration"] < 5e-2
+    floor = res["noise_floor_expected"]  # sqrt(2) sigma; the fit absorbs (3 N + 9 m) of the 2 N m degrees of freedom
+    assert 0.8 * floor < res["rmse_after_bundle_adjustment"] < 1.02 * floor, res
+    st = res["stages_s"]
+    host = {k: v for k, v in st.items() if "total" not in k and "device" not in k and "not part" not in k and "upload" not in k}
+    assert max(host.values()) < 0.25 * res["pipeline_wall_s"], host  # (measured: the largest host stage is ~7 % of the wall)
+
+
+def _timing_line(text):
+    """Full-size runs leave their timing lines under gpurun_out/ (copied to profiles/ by hand)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "fullsize_timings.txt"), "a") as fh:
+            fh.write(text + "\n")
+    print(text)
+
+
 def test_affine_driver_runs(golden, capsys):
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-reconstruction-from-multi-view-exp_amd")
     sys.path.insert(0, pkg)
