@@ -952,10 +952,13 @@ __device__ __forceinline__ void dominant_eigvec4(const double (&g)[10], double (
       }
     if (!any) break;
   }
+  // (the largest diagonal entry tracked in a scalar: `A[best][best]` with a run-time `best` put the whole of A into scratch
+  // memory -- 144 bytes per lane, stored and reloaded around every rotation of the loop above)
   int best = 0;
+  double bestv = A[0][0];
 #pragma unroll
   for (int i = 1; i < 4; ++i)
-    if (A[i][i] > A[best][best]) best = i;
+    if (A[i][i] > bestv) { best = i; bestv = A[i][i]; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = best == 0 ? V[i][0] : (best == 1 ? V[i][1] : (best == 2 ? V[i][2] : V[i][3]));
 }
@@ -1209,6 +1212,442 @@ __global__ __launch_bounds__(256) void k_dual_apply(const T *__restrict__ X, con
   block_sum_to(esum, Epart);
 }
 
+// ---------------------------------------------------------------- the depth iteration without the re-weighted matrix (round 5)
+// Round 4's iteration made ~7 passes over a 0.96 GB matrix at 5 M points x 8 images (write W = X o z normalised, Gram, rotate W V1
+// into B, Gram of B, project S = M^T W, update) for ~1.5 GB of unavoidable traffic.  For few images (n = 3 m <= 32 columns, n even:
+// the domain of the LDS-staged Gram kernel) nothing but X and z is streamed any more:
+//   k_gram_xz     Gram of W formed on the fly: a workgroup stages 128 rows of X and of z, scales the rows IN LDS (norm 1: every row
+//                 to unit length; norm 2: every image by its global scale cs), then the MFMA loop of k_gram_fused
+//   k_rotgram_xz  the refinement pass in one kernel: the same staging, B = W V1 on the matrix cores into a second LDS tile, Gram of B
+//                 from there -- B never exists in memory
+//   k_primary_xz / k_dual_gram_mfma / k_dual_apply_xz   the depth updates with S = M^T W formed per row from X, z and M (24 x 4
+//                 products) instead of read from a projection pass; the dual update also leaves the per-image sums of (x z)^2 of
+//                 the NEW depths behind (the next iteration's norm-2 scales), so k_group_sumsq runs once per loop, not once per step
+// Same arithmetic per entry as before up to the order of a few sums; oracle parity per step stays at 1e-9 (tests).
+constexpr int FZ_MAXM = 10;  // images on this path (n = 3 m <= 32)
+
+// Stage GRAM_ROWS rows of X ([rows][n]) and z ([rows][m]) and scale them in place: sx[r][c] <- x z[r][c / 3] s.
+// NORM 1: s = 1 / |row of X o z|; NORM 2: s = cs[c / 3].  Rows past the end become zeros.  sp: [GRAM_ROWS][m] scratch.
+struct FzRegs {
+  double2 xs[GRAM_ROWS * 32 / 2 / 256];
+  double2 zs[(GRAM_ROWS * FZ_MAXM / 2 + 255) / 256];
+};
+__device__ __forceinline__ void fz_load(const double *__restrict__ X, const double *__restrict__ z, long long r0, long long n_rows, int n, int m, FzRegs &R) {
+  const long long tx = n_rows * n, tz = n_rows * m, ex = r0 * n, ez = r0 * m;  // (r0 is a multiple of 128: both offsets 16-byte aligned)
+  const int nvx = GRAM_ROWS * n / 2, nvz = GRAM_ROWS * m / 2;
+#pragma unroll
+  for (int u = 0; u < (int)(sizeof(R.xs) / sizeof(double2)); ++u) {
+    const int v = threadIdx.x + 256 * u;
+    const long long i = ex + 2LL * v;
+    if (v < nvx && i + 2 <= tx) R.xs[u] = *reinterpret_cast<const double2 *>(X + i);
+    else R.xs[u] = double2{(v < nvx && i < tx) ? X[i] : 0.0, 0.0};
+  }
+#pragma unroll
+  for (int u = 0; u < (int)(sizeof(R.zs) / sizeof(double2)); ++u) {
+    const int v = threadIdx.x + 256 * u;
+    const long long i = ez + 2LL * v;
+    if (v < nvz && i + 2 <= tz) R.zs[u] = *reinterpret_cast<const double2 *>(z + i);
+    else R.zs[u] = double2{(v < nvz && i < tz) ? z[i] : 0.0, 0.0};
+  }
+}
+template <int NORM>
+__device__ __forceinline__ void fz_stage(const FzRegs &R, long long r0, long long n_rows, int n, int m, const double *__restrict__ cs,
+                                         double *sx, double *sz, double *sp) {
+  const int nvx = GRAM_ROWS * n / 2, nvz = GRAM_ROWS * m / 2;
+#pragma unroll
+  for (int u = 0; u < (int)(sizeof(R.xs) / sizeof(double2)); ++u) {
+    const int v = threadIdx.x + 256 * u;
+    if (v < nvx) *reinterpret_cast<double2 *>(sx + 2 * v) = R.xs[u];
+  }
+#pragma unroll
+  for (int u = 0; u < (int)(sizeof(R.zs) / sizeof(double2)); ++u) {
+    const int v = threadIdx.x + 256 * u;
+    if (v < nvz) *reinterpret_cast<double2 *>(sz + 2 * v) = R.zs[u];
+  }
+  __syncthreads();
+  if (NORM == 1) {  // per (row, image): z^2 |x|^2; then ONE reciprocal root per row (the full-precision divide and root per
+    // (row, image) of the first build cost 0.1 ms per pass at 5 M x 8); then the scaling
+    for (int e = threadIdx.x; e < GRAM_ROWS * m; e += 256) {
+      const int r = e / m, g = e - r * m;
+      const double *x = sx + r * n + 3 * g;
+      const double zz = sz[e];
+      sp[e] = zz * zz * (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    }
+    __syncthreads();
+    if (threadIdx.x < GRAM_ROWS) {
+      const int r = threadIdx.x;
+      double ss = 0.0;
+      for (int q = 0; q < m; ++q) ss += sp[r * m + q];
+      sp[r * m] = (r0 + r < n_rows) ? fast_rsqrt(ss) : 0.0;  // (the row's slot 0: its partials have been read by this thread alone)
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < GRAM_ROWS * m; e += 256) {
+    const int r = e / m, g = e - r * m;
+    const double f = NORM == 1 ? sz[e] * sp[r * m] : sz[e] * cs[g];
+    double *x = sx + r * n + 3 * g;
+    x[0] *= f; x[1] *= f; x[2] *= f;
+  }
+  __syncthreads();
+}
+
+// the MFMA loop of k_gram_fused over the wave's 32 staged rows (`rows` = this lane's first row in a row-major [.][n] tile)
+template <int MODE>
+__device__ __forceinline__ void fz_gram_rows(const double *rows, int n, const int *col, const bool *cok, svd_d4 *acc) {
+  constexpr int NC = MODE == 1 ? 1 : (MODE == 2 ? 3 : 2);
+#pragma unroll
+  for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
+    double v[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) v[t] = cok[t] ? rows[(4 * g) * n + col[t]] : 0.0;
+    if (MODE == 2) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0], v[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[1], v[2], acc[1], 0, 0, 0);
+    } else {
+      int q = 0;
+#pragma unroll
+      for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int u = t; u < NC; ++u, ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t], v[u], acc[q], 0, 0, 0);
+    }
+  }
+}
+
+// ROT: the refinement pass (B = W V1 on the matrix cores into a second tile, Gram of B); else the first pass (Gram of W)
+template <int MODE, int NORM, bool ROT>
+__global__ __launch_bounds__(256) void k_gram_xz(const double *__restrict__ X, const double *__restrict__ z, long long n_rows, int n, int m,
+                                                 const double *__restrict__ cs, const double *__restrict__ V1, double *__restrict__ partial) {
+  extern __shared__ double fz_lds[];
+  double *sx = fz_lds, *sz = sx + GRAM_ROWS * n, *sp = sz + GRAM_ROWS * m, *sb = sp + GRAM_ROWS * m;  // sb only when ROT
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  constexpr int NP = MODE == 1 ? 1 : (MODE == 2 ? 2 : 3);
+  constexpr int NC = MODE == 1 ? 1 : (MODE == 2 ? 3 : 2);
+  svd_d4 acc[3] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  int col[NC];
+  bool cok[NC];
+#pragma unroll
+  for (int t = 0; t < NC; ++t) {
+    const int c = MODE == 2 ? (t == 0 ? li : (t == 1 ? 8 + li : (li < 8 ? 16 + li : li - 8))) : GT * t + li;
+    cok[t] = c < n; col[t] = min(c, n - 1);
+  }
+  const int nct = (n + 15) / 16, ng = (n + 3) / 4;
+  double vb[2][8];
+  if (ROT) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int k = 4 * g + lk;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vb[c][g] = (k < n && 16 * c + li < n) ? V1[(size_t)k * n + 16 * c + li] : 0.0;
+    }
+  }
+  FzRegs R;
+  const long long r_first = (long long)blockIdx.y * GRAM_ROWS, r_stride = (long long)gridDim.y * GRAM_ROWS;
+  if (r_first < n_rows) fz_load(X, z, r_first, n_rows, n, m, R);
+  for (long long r0 = r_first; r0 < n_rows; r0 += r_stride) {
+    fz_stage<NORM>(R, r0, n_rows, n, m, cs, sx, sz, sp);
+    if (r0 + r_stride < n_rows) fz_load(X, z, r0 + r_stride, n_rows, n, m, R);  // the next step's rows travel under this step's products
+    if (ROT) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {  // the wave's two 16-row tiles: B = W V1 (as k_rotate_rows), into the wave's own rows of sb
+        const double *rows = sx + (size_t)(wave * ROWS_PER_STEP + 16 * t + li) * n;
+        svd_d4 ra[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (g >= ng) break;
+          const int k = 4 * g + lk;
+          const double a = (k < n) ? rows[k] : 0.0;
+          ra[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[0][g], ra[0], 0, 0, 0);
+          if (nct > 1) ra[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[1][g], ra[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // C/D layout: col = li, row = lk + 4 q
+          double *orow = sb + (size_t)(wave * ROWS_PER_STEP + 16 * t + lk + 4 * q) * n;
+          if (li < n) orow[li] = ra[0][q];
+          if (16 + li < n) orow[16 + li] = ra[1][q];
+        }
+      }
+      wave_sync();  // (a wave multiplies the rows of sb it wrote itself)
+      fz_gram_rows<MODE>(sb + (size_t)(wave * ROWS_PER_STEP + lk) * n, n, col, cok, acc);
+    } else {
+      fz_gram_rows<MODE>(sx + (size_t)(wave * ROWS_PER_STEP + lk) * n, n, col, cok, acc);
+    }
+    __syncthreads();
+  }
+  gram_store_partial(acc, NP, 0, NP, partial, fz_lds);  // (the staging tile: the last step ended with a barrier; NP x 8 KiB <= 128 n x 8 bytes for n >= 6 ...)
+}
+
+// per-point update of the primary scheme (k_depth_primary) with S formed from X, z and M on the fly; z in place
+__global__ __launch_bounds__(256, 2) void k_primary_xz(const double *__restrict__ X, const double *__restrict__ Mr, long long n_rows, int m,
+                                                    double *__restrict__ z, double *__restrict__ Epart) {
+  extern __shared__ double sU[];  // [3m][4], then one tile of 64 x [3m values | m depths] per wave
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) sU[q] = Mr[q];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = 3 * m, ldt = (n + m) | 1;
+  double *tile = sU + 12 * (size_t)m + (size_t)wave * 64 * ldt;
+  double esum = 0.0;
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < n_rows; base += (long long)gridDim.x * 256) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
+    tile_load(X, base, rows_here, n, tile, ldt, lane);
+    tile_load(z, base, rows_here, m, tile + n, ldt, lane);
+    wave_sync();
+    if (lane < rows_here) {
+      const double *xr = tile + lane * ldt;
+      double *zr = tile + lane * ldt + n;
+      double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s[4] = {0, 0, 0, 0}, ss = 0.0;
+      for (int k = 0; k < m; ++k) {
+        const double x0 = xr[3 * k], x1 = xr[3 * k + 1], x2 = xr[3 * k + 2], zk = zr[k];
+        const double n2 = x0 * x0 + x1 * x1 + x2 * x2, inv = fast_rsqrt(n2);
+        const double *u = sU + 12 * k;
+        double c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double d = x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i];
+          c[i] = d * inv;
+          s[i] = fma(zk, d, s[i]);  // S = M^T w, w = x z / |row|: the row scale follows below
+        }
+        ss = fma(zk * zk, n2, ss);
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = i; j < 4; ++j, ++e) g[e] = fma(c[i], c[j], g[e]);
+      }
+      const double rs = 1.0 / sqrt(ss);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] *= rs;
+      double v[4];
+      dominant_eigvec4(g, v);
+      double nrm2 = 0.0, sum = 0.0;
+      for (int k = 0; k < m; ++k) {
+        const double x0 = xr[3 * k], x1 = xr[3 * k + 1], x2 = xr[3 * k + 2];
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double *u = sU + 12 * k;
+        double xi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi = fma((x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv, v[i], xi);
+        esum += reproj_err2(u, s, x0, x1, x2);
+        nrm2 = fma(xi, xi, nrm2);
+        sum += xi;
+        zr[k] = xi * inv;
+      }
+      const double sc = (sum < 0.0 ? -1.0 : 1.0) * fast_rsqrt(nrm2);
+      for (int k = 0; k < m; ++k) zr[k] *= sc;
+    }
+    wave_sync();
+    tile_store(z, base, rows_here, m, tile + n, ldt, lane);
+    wave_sync();
+  }
+  block_sum_to(esum, Epart);
+}
+
+// dual scheme, pass 1 with V4 = S diag(1 / sigma) formed from X, z, cs and M while the rows are staged -- and the sums themselves
+// on the matrix cores.  (A first build kept k_dual_gram's form, one thread per (image, entry) walking the staged rows: 1.08-1.16 ms at
+// 5 M points x 8 images against 0.67 before S moved into the kernel -- the shares of S beside the observations doubled its LDS
+// and left two workgroups per CU; 32 rows per pass instead of 128: 0.35 against 0.44 ms at 1 M points.)
+// Per image k the 12 x 12 companion is the Gram matrix of Z_k[a] = V4[a] (x) x^_ak
+// (rows x 12): one v_mfma_f64_16x16x4_f64 per 4 rows and image with the SAME operand on both sides -- Z_k[row][li], formed per lane
+// from the staged V4 and x^ (two LDS reads, one product), column 12 of the 16-wide tile a constant 1 so that row 12 of the result
+// is the column sum of Z_k that k_dual_vec needs.  A wave keeps the m tiles of its 32 rows in registers and writes them once:
+// part[block x 4 + wave][m][256] in the C/D layout, summed in that order by k_dual_reduce_mfma (no atomics).  One thread per
+// (image, entry) walking rows through LDS took 1.08 ms at 5 M points x 8 images (0.67 before S moved into the kernel).
+__global__ __launch_bounds__(256, 2) void k_dual_gram_mfma(const double *__restrict__ X, const double *__restrict__ z, const double *__restrict__ cs,
+                                                            const double *__restrict__ Mr, double is0, double is1, double is2, double is3,
+                                                            long long n_rows, int m, double *__restrict__ part /*[gridDim.x * 4][m][256]*/) {
+  // Every WAVE stages its own 32 rows of a 128-row step (wave-private tiles, no workgroup barrier in the loop): the two waves of a
+  // SIMD drift apart and one's staging runs under the other's MFMAs.  (With the workgroup staging 128 rows together behind
+  // barriers the waves spent half their time waiting and the matrix cores were 37 % busy: 0.74 ms at 5 M x 8.)
+  extern __shared__ double sg[];
+  const int n = 3 * m, mp = m | 1, PL = ROWS_PER_STEP * mp + 8;  // shares of S: four planes [row][m | 1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int wtile = ROWS_PER_STEP * (n + m + 4) + 4 * PL;        // doubles per wave: x (normalised in place) | z | V4 | shares
+  double *sU = sg, *sx = sg + 12 * m + (size_t)wave * wtile, *sz = sx + ROWS_PER_STEP * n, *sv = sz + ROWS_PER_STEP * m, *ssh = sv + 4 * ROWS_PER_STEP;
+  for (int q = threadIdx.x; q < 12 * m; q += 256) sU[q] = Mr[q];
+  __syncthreads();
+  const double isg[4] = {is0, is1, is2, is3};
+  const int i3 = min(li / 3, 3), c3 = li - 3 * (li / 3);
+  const double one12 = li == 12 ? 1.0 : 0.0, use = li < 12 ? 1.0 : 0.0;
+  svd_d4 acc[FZ_MAXM];
+#pragma unroll
+  for (int k = 0; k < FZ_MAXM; ++k) acc[k] = svd_d4{0, 0, 0, 0};
+  constexpr int MAXX = ROWS_PER_STEP * 32 / 2 / 64, MAXZ = (ROWS_PER_STEP * FZ_MAXM / 2 + 63) / 64;
+  double2 xs[MAXX], zs[MAXZ];
+  const int nvx = ROWS_PER_STEP * n / 2, nvz = ROWS_PER_STEP * m / 2;
+  const long long tx = n_rows * n, tz = n_rows * m;
+  auto wload = [&](long long rw) {  // this wave's 32 rows from row rw on (a multiple of 32: both offsets 16-byte aligned)
+#pragma unroll
+    for (int u = 0; u < MAXX; ++u) {
+      const int v = lane + 64 * u;
+      const long long i = rw * n + 2LL * v;
+      if (v < nvx && i + 2 <= tx) xs[u] = *reinterpret_cast<const double2 *>(X + i);
+      else xs[u] = double2{(v < nvx && i < tx) ? X[i] : 0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < MAXZ; ++u) {
+      const int v = lane + 64 * u;
+      const long long i = rw * m + 2LL * v;
+      if (v < nvz && i + 2 <= tz) zs[u] = *reinterpret_cast<const double2 *>(z + i);
+      else zs[u] = double2{(v < nvz && i < tz) ? z[i] : 0.0, 0.0};
+    }
+  };
+  const long long w_first = ((long long)blockIdx.x * 4 + wave) * ROWS_PER_STEP, w_stride = (long long)gridDim.x * 4 * ROWS_PER_STEP;
+  if (w_first < n_rows) wload(w_first);
+  for (long long rw = w_first; rw < n_rows; rw += w_stride) {
+    const int nr = (int)min<long long>(ROWS_PER_STEP, n_rows - rw);
+#pragma unroll
+    for (int u = 0; u < MAXX; ++u) {
+      const int v = lane + 64 * u;
+      if (v < nvx) *reinterpret_cast<double2 *>(sx + 2 * v) = xs[u];
+    }
+#pragma unroll
+    for (int u = 0; u < MAXZ; ++u) {
+      const int v = lane + 64 * u;
+      if (v < nvz) *reinterpret_cast<double2 *>(sz + 2 * v) = zs[u];
+    }
+    wave_sync();
+    if (rw + w_stride < n_rows) wload(rw + w_stride);  // the next step's rows travel while this step is staged and multiplied
+    for (int e = lane; e < ROWS_PER_STEP * m; e += 64) {  // (row, image): normalise in place; the image's share of S = M^T w
+      const int rr = e / m, k = e - rr * m;
+      double *d = sx + rr * n + 3 * k, *sh = ssh + rr * mp + k;
+      if (rr < nr) {
+        const double x0 = d[0], x1 = d[1], x2 = d[2], f = sz[e] * cs[k];
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        d[0] = x0 * inv; d[1] = x1 * inv; d[2] = x2 * inv;
+        const double *u = sU + 12 * k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh[i * PL] = f * (x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]);
+      } else {  // rows past the end contribute zeros
+        d[0] = d[1] = d[2] = 0.0;
+        sh[0] = sh[PL] = sh[2 * PL] = sh[3 * PL] = 0.0;
+      }
+    }
+    wave_sync();
+    for (int e = lane; e < ROWS_PER_STEP * 4; e += 64) {  // V4[row][i] = (sum of the images' shares) / sigma_i
+      const int i = e / ROWS_PER_STEP, rr = e - i * ROWS_PER_STEP;
+      const double *sh = ssh + i * PL + rr * mp;
+      double t = 0.0;
+      for (int k = 0; k < m; ++k) t += sh[k];
+      sv[4 * rr + i] = t * isg[i];
+    }
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < ROWS_PER_STEP / 4; ++g) {
+      const int row = 4 * g + lk;
+      const double v4r = sv[4 * row + i3] * use, live = row < nr ? one12 : 0.0;
+      const double *xh = sx + row * n + c3;
+#pragma unroll
+      for (int k = 0; k < FZ_MAXM; ++k)
+        if (k < m) {  // (uniform)
+          const double val = fma(v4r, xh[3 * k], live);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, acc[k], 0, 0, 0);
+        }
+    }
+    wave_sync();  // (the operands have been read before the next step's rows overwrite them)
+  }
+  double *o = part + ((size_t)(blockIdx.x * 4 + wave) * m) * 256;
+#pragma unroll
+  for (int k = 0; k < FZ_MAXM; ++k)
+    if (k < m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)k * 256 + r * 64 + lane] = acc[k][r];
+    }
+}
+
+// ... -> G12[k][12][12] (symmetric, index (i, c) = 3 i + c) and colsum[k][12]: one wave per entry, the partials in order
+__global__ void k_dual_reduce_mfma(const double *__restrict__ part, int slots, int m, double *__restrict__ G12, double *__restrict__ colsum) {
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= m * 90) return;
+  const int k = t / 90, e = t - 90 * k;  // e < 78: entry (i <= j) of the 12 x 12 matrix; else column sum e - 78
+  int i = 0, j = 0;
+  if (e < 78) {
+    int rem = e;
+    while (rem >= 12 - i) { rem -= 12 - i; ++i; }
+    j = i + rem;
+  } else {
+    i = 12; j = e - 78;  // row 12 of the tile = sum over the rows of 1 x Z[.][j]
+  }
+  const double v = wave_strided_sum(part + (size_t)k * 256 + tile_elem(i, j), slots, (size_t)m * 256, lane);
+  if (lane) return;
+  if (e < 78) {
+    G12[(size_t)k * 144 + i * 12 + j] = v;
+    G12[(size_t)k * 144 + j * 12 + i] = v;
+  } else {
+    colsum[(size_t)k * 12 + j] = v;
+  }
+}
+
+// dual scheme, pass 4 (k_dual_apply) with S formed on the fly; z in place; per block the per-image sums of (x z')^2 of the NEW depths
+__global__ __launch_bounds__(256, 2) void k_dual_apply_xz(const double *__restrict__ X, const double *__restrict__ cs, double is0, double is1, double is2,
+                                                       double is3, const double *__restrict__ Mr, const double *__restrict__ w12,
+                                                       long long n_rows, int m, double *__restrict__ z, double *__restrict__ Epart,
+                                                       double *__restrict__ gpart /*[blocks][m]*/) {
+  extern __shared__ double sm[];  // U4 [3m][4], w [m][12], then one tile of 64 x [3m values | m depths] per wave
+  double *sU = sm, *sW = sm + 12 * (size_t)m;
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) { sU[q] = Mr[q]; sW[q] = w12[q]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = 3 * m, ldt = (n + m) | 1;
+  double *tile = sm + 24 * (size_t)m + (size_t)wave * 64 * ldt;
+  double esum = 0.0, gs[FZ_MAXM];
+#pragma unroll
+  for (int k = 0; k < FZ_MAXM; ++k) gs[k] = 0.0;
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < n_rows; base += (long long)gridDim.x * 256) {
+    const int rows_here = (int)min<long long>(64, n_rows - base);
+    tile_load(X, base, rows_here, n, tile, ldt, lane);
+    tile_load(z, base, rows_here, m, tile + n, ldt, lane);
+    wave_sync();
+    if (lane < rows_here) {
+      const double *xr = tile + lane * ldt;
+      double *zr = tile + lane * ldt + n;
+      double s[4] = {0, 0, 0, 0};
+      for (int k = 0; k < m; ++k) {
+        const double x0 = xr[3 * k], x1 = xr[3 * k + 1], x2 = xr[3 * k + 2], f = zr[k] * cs[k];
+        const double *u = sU + 12 * k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = fma(f, x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i], s[i]);
+      }
+      const double v4[4] = {s[0] * is0, s[1] * is1, s[2] * is2, s[3] * is3};
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < FZ_MAXM; ++k) {  // (fully unrolled: gs[] stays in registers)
+        if (k < m) {
+        const double x0 = xr[3 * k], x1 = xr[3 * k + 1], x2 = xr[3 * k + 2];
+        const double n2 = x0 * x0 + x1 * x1 + x2 * x2, inv = fast_rsqrt(n2);
+        const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
+        const double *w = sW + 12 * k;
+        double xi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi = fma(v4[i], h0 * w[3 * i] + h1 * w[3 * i + 1] + h2 * w[3 * i + 2], xi);
+        sum += xi;
+        const double zn = xi * inv;
+        zr[k] = zn;
+        gs[k] = fma(zn * zn, n2, gs[k]);  // (the row's sign flip below does not change it)
+        esum += reproj_err2(sU + 12 * k, s, x0, x1, x2);
+        }
+      }
+      if (sum < 0.0)
+        for (int k = 0; k < m; ++k) zr[k] = -zr[k];  // ref :217
+    }
+    wave_sync();
+    tile_store(z, base, rows_here, m, tile + n, ldt, lane);
+    wave_sync();
+  }
+  block_sum_to(esum, Epart);
+#pragma unroll
+  for (int k = 0; k < FZ_MAXM; ++k) {
+    if (k < m) {  // (m is uniform)
+      __syncthreads();
+      block_sum_to(gs[k], gpart + k * (size_t)gridDim.x);  // gpart[k][block]: k_group_scale_t sums a row in block order
+    }
+  }
+}
+
+// cs[g] = 1 / (sum over the blocks, in order, of gpart[g][block])
+__global__ void k_group_scale_t(const double *__restrict__ gpart, int blocks, int ng, double *__restrict__ cs) {
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= ng) return;
+  const double t = wave_strided_sum(gpart + (size_t)g * blocks, blocks, 1, lane);
+  if (lane == 0) cs[g] = 1.0 / t;
+}
+
 __global__ void k_depth_error(const double *__restrict__ Epart, int blocks, double count, double f0, double *__restrict__ out) {
   const double t = wave_strided_sum(Epart, blocks, 1, (int)threadIdx.x);  // one wave
   if (threadIdx.x == 0) out[0] = f0 * sqrt(t / count);  // ref :56
@@ -1229,6 +1668,7 @@ struct mvsvd_handle {
   double *dgs = nullptr;              // column-group partial sums and scales
   bool base_loaded = false;
   int depth_group = 0;                // mvsvd_depth_begin: columns per image (3); 0 = no depth loop started
+  bool cs_valid = false;              // fused depth iteration: the per-image scales of norm 2 belong to the depths in dz
   double *ddep = nullptr;             // depth iteration: error partials, 12 x 12 problems, vectors (one allocation)
   int *ddflag = nullptr;
   int chunks = 1, rank_cap = 0;
@@ -1481,6 +1921,126 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
   }
   return MVBA_OK;
 }
+// The iteration without the re-weighted matrix (see k_gram_xz): fp64, n = 3 m <= 32 columns, n even.
+bool fused_depth_ok(const mvsvd_handle *h) {
+  return h->dtype == 1 && h->n <= 32 && h->n % 2 == 0 && h->n / 3 <= FZ_MAXM && h->base_rows >= 256 && !getenv("MVSVD_DEPTH_UNFUSED");
+}
+
+template <int MODE, int NORM>
+void launch_gram_xz(mvsvd_handle *h, bool rot, int chunks, const double *cs) {
+  const int n = h->n, m = n / 3;
+  constexpr int NP = MODE == 1 ? 1 : (MODE == 2 ? 2 : 3);
+  const size_t lds = std::max<size_t>(sizeof(double) * (size_t)GRAM_ROWS * ((rot ? 2 : 1) * n + 2 * m), (size_t)NP * 8192);
+  if (rot)
+    hipLaunchKernelGGL((k_gram_xz<MODE, NORM, true>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
+                       (const double *)h->dV1, h->dpart);
+  else
+    hipLaunchKernelGGL((k_gram_xz<MODE, NORM, false>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
+                       (const double *)nullptr, h->dpart);
+  const int n_tiles = (n + GT - 1) / GT, slices = std::min(chunks, GRAM_SLICES);
+  hipLaunchKernelGGL(k_gram_reduce, dim3(NP, slices), dim3(256), 0, h->st, h->dpart, chunks, NP, h->dpart2);
+  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dpart2, slices, NP, n_tiles, MODE == 2 ? 1 : 0, h->dG, n);
+}
+void gram_xz(mvsvd_handle *h, int norm, bool rot, int chunks, const double *cs) {
+  const int n = h->n;
+  if (n <= 16) { if (norm == 1) launch_gram_xz<1, 1>(h, rot, chunks, cs); else launch_gram_xz<1, 2>(h, rot, chunks, cs); }
+  else if (n <= 24) { if (norm == 1) launch_gram_xz<2, 1>(h, rot, chunks, cs); else launch_gram_xz<2, 2>(h, rot, chunks, cs); }
+  else { if (norm == 1) launch_gram_xz<3, 1>(h, rot, chunks, cs); else launch_gram_xz<3, 2>(h, rot, chunks, cs); }
+}
+
+int depth_step_fused(mvsvd_handle *h, int method, double f0, double *E, double *timings) {
+  const int n = h->n, m = n / 3;
+  const long long rows = h->base_rows;
+  const size_t nn = (size_t)n * n;
+  hipStream_t st = h->st;
+  const double *dX = (const double *)h->dX;
+  double *dz = (double *)h->dz;
+  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
+  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
+  const size_t dual_part = (size_t)512 * 4 * m * 256;  // k_dual_gram_mfma: a 16 x 16 tile per wave and image, at most 512 workgroups
+  const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + dual_part + (size_t)FZ_MAXM * DEPTH_BLOCKS;
+  if (!h->ddep) MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));  // (the fused path is chosen per handle: `need` never changes)
+  if (!h->ddflag) MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
+  double *Epart = h->ddep, *Eout = Epart + DEPTH_BLOCKS, *G12 = Eout + 8, *V12 = G12 + (size_t)m * 144, *colsum = V12 + (size_t)m * 144,
+         *w12 = colsum + (size_t)m * 12, *gpart = w12 + (size_t)m * 12, *gsum = gpart + dual_part;
+  if (method == 2 && !h->cs_valid) {  // the per-image scales of the depths the loop holds (first dual step, or after primary steps)
+    const int gb = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, rows / 64 + 1));
+    hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gb), dim3(256), 0, st, dX, (const double *)dz, rows, n, 3, h->dgs);
+    hipLaunchKernelGGL(k_group_scale, dim3((m + 3) / 4), dim3(256), 0, st, h->dgs, gb, m, cs);
+    h->cs_valid = true;
+  }
+  const int chunks = chunks_for(rows, n);
+  hipEventRecord(h->ev[1], st);
+  gram_xz(h, method, false, chunks, cs);
+  hipEventRecord(h->ev[2], st);
+  launch_jacobi(h, h->dV1, 1e-15);
+  hipEventRecord(h->ev[3], st);
+  gram_xz(h, method, true, chunks, cs);  // B = W V1 never leaves the LDS
+  launch_jacobi(h, h->dMr, 1e-15);
+  hipLaunchKernelGGL(k_rotate<double>, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, st, h->dV1, (long long)n, n, (const double *)nullptr, h->dMr, h->dV);
+  hipEventRecord(h->ev[4], st);
+  // eigenvalues -> host, sort, the rank-4 basis with the same deterministic sign as mvsvd_run
+  std::vector<double> hG(nn), hV(nn), Mg((size_t)n * 4);
+  MVBA_HIP(hipMemcpyAsync(hG.data(), h->dG, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipMemcpyAsync(hV.data(), h->dV, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return hG[(size_t)a * n + a] > hG[(size_t)b * n + b]; });
+  double is[4];
+  for (int i = 0; i < 4; ++i) {
+    const int col = order[i];
+    const double sg2 = hG[(size_t)col * n + col];
+    if (method == 2 && !(sg2 > 0.0)) return fail(MVBA_ERR_SINGULAR, "measurement matrix has rank < 4");
+    is[i] = 1.0 / std::sqrt(std::max(sg2, 1e-300));
+    int big = 0;
+    for (int c = 1; c < n; ++c)
+      if (std::fabs(hV[(size_t)c * n + col]) > std::fabs(hV[(size_t)big * n + col])) big = c;
+    const double sg = hV[(size_t)big * n + col] < 0.0 ? -1.0 : 1.0;
+    for (int c = 0; c < n; ++c) Mg[(size_t)c * 4 + i] = sg * hV[(size_t)c * n + col];
+  }
+  MVBA_HIP(hipMemcpyAsync(h->dMr, Mg.data(), sizeof(double) * (size_t)n * 4, hipMemcpyHostToDevice, st));
+  const int pgrid = (int)std::max<long long>(1, std::min<long long>(DEPTH_BLOCKS, (rows + 255) / 256));
+  const size_t tile_bytes = sizeof(double) * 4 * 64 * (size_t)((n + m) | 1) + 16;
+  hipEventRecord(h->ev[6], st);
+  if (method == 1) {
+    hipLaunchKernelGGL(k_primary_xz, dim3(pgrid), dim3(256), sizeof(double) * 12 * m + tile_bytes, st, dX, h->dMr, rows, m, dz, Epart);
+    h->cs_valid = false;
+  } else {
+    MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
+    const int mblocks = (int)std::max<long long>(1, std::min<long long>(512, (rows + GRAM_ROWS - 1) / GRAM_ROWS));  // two workgroups per CU
+    const size_t mlds = sizeof(double) * (12 * (size_t)m + 4 * ((size_t)ROWS_PER_STEP * (n + m + 4) + 4 * ((size_t)ROWS_PER_STEP * (m | 1) + 8)));
+    hipLaunchKernelGGL(k_dual_gram_mfma, dim3(mblocks), dim3(256), mlds, st, dX, (const double *)dz, cs, h->dMr, is[0], is[1], is[2], is[3], rows, m, gpart);
+    hipLaunchKernelGGL(k_dual_reduce_mfma, dim3((m * 90 + 3) / 4), dim3(256), 0, st, gpart, mblocks * 4, m, G12, colsum);
+    hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
+    hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
+    hipLaunchKernelGGL(k_dual_apply_xz, dim3(pgrid), dim3(256), sizeof(double) * 24 * m + tile_bytes, st, dX, cs, is[0], is[1], is[2], is[3], h->dMr, w12, rows, m,
+                       dz, Epart, gsum);
+    hipLaunchKernelGGL(k_group_scale_t, dim3((m + 3) / 4), dim3(256), 0, st, gsum, pgrid, m, cs);  // the next iteration's scales
+  }
+  hipLaunchKernelGGL(k_depth_error, dim3(1), dim3(64), 0, st, Epart, pgrid, (double)rows * (double)m, f0, Eout);
+  hipEventRecord(h->ev[7], st);
+  MVBA_HIP(hipGetLastError());
+  int fl = 0;
+  MVBA_HIP(hipMemcpyAsync(E, Eout, sizeof(double), hipMemcpyDeviceToHost, st));
+  if (method == 2) MVBA_HIP(hipMemcpyAsync(&fl, h->ddflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
+  h->loaded = false;  // (no re-weighted matrix was written: dW holds nothing that belongs to these depths)
+  if (fl) return fail(MVBA_ERR_SINGULAR, "depth iteration: an image's 12 x 12 companion matrix has no positive eigenvalue");
+  if (timings) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->ev[6], h->ev[7]); timings[0] = ms;  // depth update
+    hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); timings[1] = ms;  // first Gram pass
+    hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); timings[2] = ms;  // Jacobi (first pass)
+    timings[3] = 0.0;                                                // (no projection pass)
+    int sw = 0;
+    hipMemcpy(&sw, h->dsw, sizeof(int), hipMemcpyDeviceToHost);
+    timings[4] = sw;
+    hipEventElapsedTime(&ms, h->ev[3], h->ev[4]); timings[5] = ms;  // refinement pass (rotate + Gram fused, Jacobi, V1 V2)
+  }
+  return MVBA_OK;
+}
+
 }  // namespace
 
 
@@ -1518,7 +2078,10 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   for (const void *f : {(const void *)k_scale_rows_tiled<float>, (const void *)k_scale_rows_tiled<double>, (const void *)k_depth_primary<float, true>,
                         (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
-                        (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>})
+                        (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>, (const void *)k_primary_xz, (const void *)k_dual_gram_mfma,
+                        (const void *)k_dual_apply_xz, (const void *)k_gram_xz<1, 1, true>, (const void *)k_gram_xz<1, 2, true>, (const void *)k_gram_xz<2, 1, true>,
+                        (const void *)k_gram_xz<2, 2, true>, (const void *)k_gram_xz<3, 1, true>, (const void *)k_gram_xz<3, 2, true>, (const void *)k_gram_xz<3, 1, false>,
+                        (const void *)k_gram_xz<3, 2, false>})
     SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX));
 #undef SVD_TRY
   *out = h;
@@ -1618,6 +2181,7 @@ int mvsvd_depth_begin(mvsvd_handle *h, int32_t group) {
   else hipLaunchKernelGGL(k_fill<double>, dim3(grid), dim3(256), 0, h->st, (double *)h->dz, cnt, 1.0);
   MVBA_HIP(hipGetLastError());
   h->depth_group = 3;
+  h->cs_valid = false;
   return MVBA_OK;
 }
 
@@ -1627,6 +2191,7 @@ int mvsvd_depth_step(mvsvd_handle *h, int32_t method, double f0, double *E, doub
   if (method != 1 && method != 2) return fail(MVBA_ERR_BADARG, "method must be 1 (primary) or 2 (dual)");
   if (h->n < 6) return fail(MVBA_ERR_BADARG, "the rank-4 depth iteration needs at least 2 images (3 m >= 4 columns, as the reference's)");
   MVBA_HIP(hipSetDevice(h->device));
+  if (fused_depth_ok(h)) return depth_step_fused(h, method, f0, E, timings_ms);
   return h->dtype == 0 ? depth_step<float>(h, method, f0, E, timings_ms) : depth_step<double>(h, method, f0, E, timings_ms);
 }
 

@@ -297,8 +297,20 @@ def depth_iteration(rows, m=8):
                 wall = (time.perf_counter() - t0) * 1e3
                 if best is None or wall < best[0]:
                     best = (wall, tm, E)
+            # algorithmic bytes of one iteration: the factorisation needs the eigenvectors before any depth can be
+            # updated, so X and z are read at least twice (Gram pass, update pass) and z is written once: (2 x 24 + 3 x 8) m = 72 m
+            # bytes per point in fp64.  What this build streams: + the refinement pass of the fp64 factorisation (32 m) and, for the
+            # dual scheme, the per-image companion pass (32 m): 104 m / 136 m bytes per point.
+            alg = 72.0 * m * rows
+            streamed = (104.0 if method == 1 else 136.0) * m * rows
             out[name] = {"wall_ms_per_iteration": best[0], "reprojection_error": best[2],
-                         "device_ms": {k: best[1][k] for k in ("gram_ms", "jacobi_ms", "refine_ms", "project_ms", "depth_ms")}}
+                         "device_ms": {k: best[1][k] for k in ("gram_ms", "jacobi_ms", "refine_ms", "project_ms", "depth_ms")},
+                         "roofline": {"bound": "hbm", "achieved": alg / (best[0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": alg / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": alg,
+                                      "streamed_bytes_per_iteration": streamed, "streamed_GBs": streamed / (best[0] * 1e-3) / 1e9,
+                                      "note": "wall time of the whole iteration (five streaming passes, three small eigenproblems, one host "
+                                              "round trip for the eigenvalue order); traffic not measured by PMC (null in the contract's sense)",
+                                      "traffic": None}}
     finally:
         ws.close()
     return out
@@ -451,7 +463,7 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--svd-rows", type=int, default=5_000_000, help="config-5 SVD rows (0 = skip)")
-    ap.add_argument("--depth-rows", type=int, default=1_000_000, help="points of the projective-depth iteration leg (0 = skip)")
+    ap.add_argument("--depth-rows", type=int, default=5_000_000, help="points of the projective-depth iteration leg (0 = skip; 5 M x 8 images fp64 is the size DESIGN.md quotes)")
     ap.add_argument("--no-config4-shard-leg", action="store_true",
                     help="N=1 default run: skip the short leg on config 4's per-GPU shard (~6 s: scene 1.7 s, create 0.3 s, 4 LM iterations)")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
