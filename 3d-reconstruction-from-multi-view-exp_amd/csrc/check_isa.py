@@ -126,6 +126,11 @@ def check_flow_posts(text):
         if not ok:
             errs.append(f"k_chol_backsolve_all<true>: a progress word may overtake the data it announces (no s_waitcnt vmcnt(0) "
                         f"between the last vector-memory operation and the barrier before `{lines[i]}`)")
+    # the shared vector travels between workgroups through memory with sc1 loads and stores (a plain load could hit a stale line, a
+    # plain store would sit in the L2): the annotations must still be there (which accesses are the vector's cannot be told from
+    # the ISA -- the tiles of L are 8-byte loads too --, so this guards against their silent disappearance, not against a missing one)
+    if not any(re.match(r"global_load_dwordx2\b.*\bsc1\b", ln) for ln in lines) or not any(re.match(r"global_store_dwordx2\b.*\bsc1\b", ln) for ln in lines):
+        errs.append("k_chol_backsolve_all<true>: no sc1 load / store of the shared vector found")
     if any(ln.startswith(("buffer_wbl2", "buffer_inv")) for ln in lines):
         errs.append("k_chol_backsolve_all<true>: a device-wide fence (buffer_wbl2 / buffer_inv) crept back in")
     return errs
