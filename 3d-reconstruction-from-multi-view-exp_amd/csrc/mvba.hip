@@ -860,29 +860,33 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 #if defined(MVBA_KO_GATHER)  // (timing-only knock-out: every gather fetches row 0 of its array -- one line, always in L2 -- instead of its row)
       row = 0;
 #endif
-      const unsigned o = ((unsigned)row << 7) + slot16;
 #if defined(MVBA_KO_DMA)     // (timing-only knock-out: no record / point-row gather at all; the counted waits are adjusted below)
-      (void)o; (void)base; (void)lds;
+      (void)row; (void)slot16; (void)base; (void)lds;
 #else
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(o), "s"(base), "s"(lds) : "memory");
+      // (the byte offset row * 128 + slot16 is formed BETWEEN the write of M0 and the gather that reads it: the one wait state the
+      // hardware asks for there was an s_nop in rounds 3-4 -- eight issue slots per step for nothing)
+      unsigned o;
+      asm volatile("s_mov_b32 m0, %4\n\tv_lshl_add_u32 %0, %1, 7, %2\n\tglobal_load_lds_dwordx4 %0, %3" : "=&v"(o) : "v"(row), "v"(slot16), "s"(base), "s"(lds) : "memory");
 #endif
     };
     const unsigned lane16 = (unsigned)min(lane, 15) << 4;
-    auto dma_idx = [&](int st) {  // the 256-byte index row of step st -> ring slot st % 3 (lanes 0..15, 16 bytes each)
+    auto dma_idx = [&](int st, unsigned ring_off) {  // the 256-byte index row of step st -> ring slot st % 3 = byte offset ring_off (lanes 0..15, 16 bytes each)
 #if defined(MVBA_KO_IDX)  // (timing-only knock-out: always the wave's FIRST index row -- in L2 after the first touch -- instead of a new line from HBM)
       const int *src = xbase + (size_t)min(st & 1, last_st) * SLOT_IDX;
 #else
       const int *src = xbase + (size_t)min(st, last_st) * SLOT_IDX;  // wave-uniform
 #endif
-      const unsigned dst = ldsx0 + (unsigned)(st % SLOT_IDX_RING) * (SLOT_IDX * 4);
+      const unsigned dst = ldsx0 + ring_off;
       if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(dst) : "memory");
     };
     const unsigned ds16 = (unsigned)dslot << 4, ps16 = (unsigned)pslot << 4, ps16b = (unsigned)pslot2 << 4;
     const int xr0 = min(drow, PSTEP - 1), xr1 = min(9 + drow, PSTEP - 1), xr2 = min(18 + drow, PSTEP - 1);  // this lane's rows of a step
     const int xa0 = 2 * PSTEP + min(prow, PSTEP - 1), xa1 = 2 * PSTEP + min(prow2, PSTEP - 1), xl = min(lane, PSTEP - 1);
-    auto issue_step = [&](int st) {  // gathers of step st from its indices in the ring (landed: the caller's wait saw to it)
-      const int *x = xring + (st % SLOT_IDX_RING) * SLOT_IDX;
-      const unsigned buf = lds0 + (unsigned)(st % 3) * BUFSZ;
+    // (which of the three buffers / ring slots a step uses -- step % 3 -- is carried as three byte offsets that rotate once per
+    // iteration: the loop computed the remainder three times a step before, a dozen scalar instructions)
+    auto issue_step = [&](unsigned ring_off, unsigned buf_off) {  // gathers of a step from its indices in the ring (landed: the caller's wait saw to it)
+      const int *x = reinterpret_cast<const int *>(reinterpret_cast<const char *>(xring) + ring_off);
+      const unsigned buf = lds0 + buf_off;
       const unsigned kb = buf, lb = buf + LB_OFF, pb_ = buf + PB_OFF;
       const int k0 = x[xr0], k1 = x[xr1], k2 = x[xr2];
       if (!DIAG) {
@@ -910,13 +914,15 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
         if (lane < 5 * PSTEP - 64) dma(a1, ps16b, PB, pb_ + 1024);
       }
     };
-    dma_idx(0);
-    dma_idx(1);
+    constexpr unsigned RING_B = SLOT_IDX * 4;
+    dma_idx(0, 0);
+    dma_idx(1, RING_B);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_step(0);
-    dma_idx(2);
-    issue_step(min(1, last_st));
-    dma_idx(3);
+    issue_step(0, 0);
+    dma_idx(2, 2 * RING_B);
+    issue_step(last_st >= 1 ? RING_B : 0, BUFSZ);  // (a one-step wave: the clamped step 0 once more, into the buffer nobody reads)
+    dma_idx(3, 0);
+    unsigned b0 = 0, b1 = BUFSZ, b2 = 2 * BUFSZ, r0 = 0, r1 = RING_B, r2 = 2 * RING_B;  // offsets of step st, st + 1, st + 2
 #ifdef MVBA_SLOT_TRACE  // where a step's cycles go: one s_memtime stamp (with its own lgkmcnt(0): ~40 cycles) between the phases
 #define TR_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, tA, tB, tC, tD, tE, tF, tL0, tL1;
@@ -936,11 +942,12 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
       TR_STAMP(tB);
       pace_at(st * PSTEP);
       TR_STAMP(tC);
-      issue_step(st + 2);  // (past the end: the ring slot holds the indices of the clamped last step, its rows land in a buffer nobody reads)
+      issue_step(r2, b2);  // step st + 2 (past the end: the ring slot holds the indices of the clamped last step, its rows land in a buffer nobody reads)
       TR_STAMP(tD);
-      dma_idx(st + 4);
+      dma_idx(st + 4, r1);  // (st + 4) % 3 = (st + 1) % 3: the slot whose indices were read an iteration ago
       TR_STAMP(tE);
-      compute(wbuf + (st % 3) * BUFSZ, PSTEP);
+      compute(wbuf + b0, PSTEP);
+      { const unsigned tb = b0, tr = r0; b0 = b1; b1 = b2; b2 = tb; r0 = r1; r1 = r2; r2 = tr; }
 #ifdef MVBA_SLOT_TRACE
       TR_STAMP(tF);
       ph0 += tB - tA; ph1 += tC - tB; ph2 += tD - tC; ph3 += tE - tD; ph4 += tF - tE;
