@@ -9,7 +9,7 @@ cp gpurun_out/${tag}_pmc_config3.json profiles/pmc_config3.json
 bash tools/final_profile.sh ${tag}4 pmc_config4_shard --config4-shard || exit 1
 cp gpurun_out/${tag}4_pmc_config4_shard.json profiles/pmc_config4_shard.json
 timeout -k 10 500 python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err || { tail -5 gpurun_out/${tag}_bench_default.err; exit 1; }
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_config3.json 2> /dev/null || exit 1
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config4-shard-leg > gpurun_out/${tag}_bench_config3.json 2> /dev/null || exit 1
 timeout -k 10 300 python bench.py --config4-shard --steps 10 --warmup 3 --no-cpu-baseline --svd-rows 0 > gpurun_out/${tag}_bench_config4_shard.json 2> /dev/null || exit 1
 python - <<PY
 import json
