@@ -20,6 +20,8 @@ for d in sys.argv[4:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            if k.startswith("void "):  # a template instance: `void k_resid_jac<false>` -> the kernel's name (round 5: K1 / K5 / K6 are templates)
+                k = k[5:].split("<")[0]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = {"FETCH_SIZE": "FETCH_SIZE_KiB", "WRITE_SIZE": "WRITE_SIZE_KiB", "TCC_HIT_sum": "TCC_HIT", "TCC_MISS_sum": "TCC_MISS",
          "TCC_EA0_RDREQ_sum": "TCC_EA0_RDREQ"}
