@@ -1314,9 +1314,11 @@ __device__ __forceinline__ void fz_gram_rows(const double *rows, int n, const in
 }
 
 // ROT: the refinement pass (B = W V1 on the matrix cores into a second tile, Gram of B); else the first pass (Gram of W)
-template <int MODE, int NORM, bool ROT>
-__global__ __launch_bounds__(256) void k_gram_xz(const double *__restrict__ X, const double *__restrict__ z, long long n_rows, int n, int m,
+template <int M, int NORM, bool ROT>  // M images at compile time (the staging's divisions by m become shifts and multiplies)
+__global__ __launch_bounds__(256) void k_gram_xz(const double *__restrict__ X, const double *__restrict__ z, long long n_rows, int n_rt, int m_rt,
                                                  const double *__restrict__ cs, const double *__restrict__ V1, double *__restrict__ partial) {
+  constexpr int m = M, n = 3 * M, MODE = n <= 16 ? 1 : (n <= 24 ? 2 : 3);
+  (void)n_rt; (void)m_rt;
   extern __shared__ double fz_lds[];
   double *sx = fz_lds, *sz = sx + GRAM_ROWS * n, *sp = sz + GRAM_ROWS * m, *sb = sp + GRAM_ROWS * m;  // sb only when ROT
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
@@ -1450,9 +1452,12 @@ __global__ __launch_bounds__(256, 2) void k_primary_xz(const double *__restrict_
 // is the column sum of Z_k that k_dual_vec needs.  A wave keeps the m tiles of its 32 rows in registers and writes them once:
 // part[block x 4 + wave][m][256] in the C/D layout, summed in that order by k_dual_reduce_mfma (no atomics).  One thread per
 // (image, entry) walking rows through LDS took 1.08 ms at 5 M points x 8 images (0.67 before S moved into the kernel).
+template <int M>  // the image count at compile time (the fused path has m in {2, 4, 6, 8, 10}): no division per staging task, no branch between MFMAs
 __global__ __launch_bounds__(256, 2) void k_dual_gram_mfma(const double *__restrict__ X, const double *__restrict__ z, const double *__restrict__ cs,
                                                             const double *__restrict__ Mr, double is0, double is1, double is2, double is3,
-                                                            long long n_rows, int m, double *__restrict__ part /*[gridDim.x * 4][m][256]*/) {
+                                                            long long n_rows, int m_rt, double *__restrict__ part /*[gridDim.x * 4][m][256]*/) {
+  constexpr int m = M;
+  (void)m_rt;
   // Every WAVE stages its own 32 rows of a 128-row step (wave-private tiles, no workgroup barrier in the loop): the two waves of a
   // SIMD drift apart and one's staging runs under the other's MFMAs.  (With the workgroup staging 128 rows together behind
   // barriers the waves spent half their time waiting and the matrix cores were 37 % busy: 0.74 ms at 5 M x 8.)
@@ -1466,10 +1471,10 @@ __global__ __launch_bounds__(256, 2) void k_dual_gram_mfma(const double *__restr
   const double isg[4] = {is0, is1, is2, is3};
   const int i3 = min(li / 3, 3), c3 = li - 3 * (li / 3);
   const double one12 = li == 12 ? 1.0 : 0.0, use = li < 12 ? 1.0 : 0.0;
-  svd_d4 acc[FZ_MAXM];
+  svd_d4 acc[M];
 #pragma unroll
-  for (int k = 0; k < FZ_MAXM; ++k) acc[k] = svd_d4{0, 0, 0, 0};
-  constexpr int MAXX = ROWS_PER_STEP * 32 / 2 / 64, MAXZ = (ROWS_PER_STEP * FZ_MAXM / 2 + 63) / 64;
+  for (int k = 0; k < M; ++k) acc[k] = svd_d4{0, 0, 0, 0};
+  constexpr int MAXX = (ROWS_PER_STEP * 3 * M / 2 + 63) / 64, MAXZ = (ROWS_PER_STEP * M / 2 + 63) / 64;
   double2 xs[MAXX], zs[MAXZ];
   const int nvx = ROWS_PER_STEP * n / 2, nvz = ROWS_PER_STEP * m / 2;
   const long long tx = n_rows * n, tz = n_rows * m;
@@ -1535,21 +1540,19 @@ __global__ __launch_bounds__(256, 2) void k_dual_gram_mfma(const double *__restr
       const double v4r = sv[4 * row + i3] * use, live = row < nr ? one12 : 0.0;
       const double *xh = sx + row * n + c3;
 #pragma unroll
-      for (int k = 0; k < FZ_MAXM; ++k)
-        if (k < m) {  // (uniform)
-          const double val = fma(v4r, xh[3 * k], live);
-          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, acc[k], 0, 0, 0);
-        }
+      for (int k = 0; k < M; ++k) {
+        const double val = fma(v4r, xh[3 * k], live);
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, acc[k], 0, 0, 0);
+      }
     }
     wave_sync();  // (the operands have been read before the next step's rows overwrite them)
   }
   double *o = part + ((size_t)(blockIdx.x * 4 + wave) * m) * 256;
 #pragma unroll
-  for (int k = 0; k < FZ_MAXM; ++k)
-    if (k < m) {
+  for (int k = 0; k < M; ++k) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[(size_t)k * 256 + r * 64 + lane] = acc[k][r];
-    }
+    for (int r = 0; r < 4; ++r) o[(size_t)k * 256 + r * 64 + lane] = acc[k][r];
+  }
 }
 
 // ... -> G12[k][12][12] (symmetric, index (i, c) = 3 i + c) and colsum[k][12]: one wave per entry, the partials in order
@@ -1576,6 +1579,8 @@ __global__ void k_dual_reduce_mfma(const double *__restrict__ part, int slots, i
 }
 
 // dual scheme, pass 4 (k_dual_apply) with S formed on the fly; z in place; per block the per-image sums of (x z')^2 of the NEW depths
+// (the image count stays a run-time value HERE: with it at compile time hipcc hoists the LDS reads of all M unrolled iterations --
+// the w and U rows, 24 doubles per image -- in front of the loop: 256 registers + 400-600 bytes of scratch, 2.0 ms instead of 0.5)
 __global__ __launch_bounds__(256, 2) void k_dual_apply_xz(const double *__restrict__ X, const double *__restrict__ cs, double is0, double is1, double is2,
                                                        double is3, const double *__restrict__ Mr, const double *__restrict__ w12,
                                                        long long n_rows, int m, double *__restrict__ z, double *__restrict__ Epart,
@@ -1631,13 +1636,20 @@ __global__ __launch_bounds__(256, 2) void k_dual_apply_xz(const double *__restri
     wave_sync();
   }
   block_sum_to(esum, Epart);
+  // the m per-image sums: a fixed shuffle tree per wave, the four waves added in order by one thread per image -- two barriers
+  // (m block-wide trees of eight barriers each were a tenth of this kernel: a block lives for ten rows per thread)
+  __shared__ double s_gs[4][FZ_MAXM];
 #pragma unroll
   for (int k = 0; k < FZ_MAXM; ++k) {
     if (k < m) {  // (m is uniform)
-      __syncthreads();
-      block_sum_to(gs[k], gpart + k * (size_t)gridDim.x);  // gpart[k][block]: k_group_scale_t sums a row in block order
+      double v = gs[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) s_gs[wave][k] = v;
     }
   }
+  __syncthreads();
+  if ((int)threadIdx.x < m) gpart[threadIdx.x * (size_t)gridDim.x + blockIdx.x] = (s_gs[0][threadIdx.x] + s_gs[1][threadIdx.x]) + (s_gs[2][threadIdx.x] + s_gs[3][threadIdx.x]);
 }
 
 // cs[g] = 1 / (sum over the blocks, in order, of gpart[g][block])
@@ -1926,26 +1938,40 @@ bool fused_depth_ok(const mvsvd_handle *h) {
   return h->dtype == 1 && h->n <= 32 && h->n % 2 == 0 && h->n / 3 <= FZ_MAXM && h->base_rows >= 256 && !getenv("MVSVD_DEPTH_UNFUSED");
 }
 
-template <int MODE, int NORM>
+template <int M, int NORM>
 void launch_gram_xz(mvsvd_handle *h, bool rot, int chunks, const double *cs) {
-  const int n = h->n, m = n / 3;
+  constexpr int n = 3 * M, m = M, MODE = n <= 16 ? 1 : (n <= 24 ? 2 : 3);
   constexpr int NP = MODE == 1 ? 1 : (MODE == 2 ? 2 : 3);
   const size_t lds = std::max<size_t>(sizeof(double) * (size_t)GRAM_ROWS * ((rot ? 2 : 1) * n + 2 * m), (size_t)NP * 8192);
+  static bool attr_set = false;
+  if (!attr_set) {  // (the refinement form of 10 images stages 80 KiB)
+    hipFuncSetAttribute((const void *)k_gram_xz<M, NORM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX);
+    hipFuncSetAttribute((const void *)k_gram_xz<M, NORM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX);
+    attr_set = true;
+  }
   if (rot)
-    hipLaunchKernelGGL((k_gram_xz<MODE, NORM, true>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
+    hipLaunchKernelGGL((k_gram_xz<M, NORM, true>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
                        (const double *)h->dV1, h->dpart);
   else
-    hipLaunchKernelGGL((k_gram_xz<MODE, NORM, false>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
+    hipLaunchKernelGGL((k_gram_xz<M, NORM, false>), dim3(1, chunks), dim3(256), lds, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, n, m, cs,
                        (const double *)nullptr, h->dpart);
   const int n_tiles = (n + GT - 1) / GT, slices = std::min(chunks, GRAM_SLICES);
   hipLaunchKernelGGL(k_gram_reduce, dim3(NP, slices), dim3(256), 0, h->st, h->dpart, chunks, NP, h->dpart2);
   hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dpart2, slices, NP, n_tiles, MODE == 2 ? 1 : 0, h->dG, n);
 }
+template <int NORM>
+void gram_xz_m(mvsvd_handle *h, bool rot, int chunks, const double *cs) {
+  switch (h->n / 3) {
+    case 2: launch_gram_xz<2, NORM>(h, rot, chunks, cs); break;
+    case 4: launch_gram_xz<4, NORM>(h, rot, chunks, cs); break;
+    case 6: launch_gram_xz<6, NORM>(h, rot, chunks, cs); break;
+    case 8: launch_gram_xz<8, NORM>(h, rot, chunks, cs); break;
+    default: launch_gram_xz<10, NORM>(h, rot, chunks, cs); break;
+  }
+}
 void gram_xz(mvsvd_handle *h, int norm, bool rot, int chunks, const double *cs) {
-  const int n = h->n;
-  if (n <= 16) { if (norm == 1) launch_gram_xz<1, 1>(h, rot, chunks, cs); else launch_gram_xz<1, 2>(h, rot, chunks, cs); }
-  else if (n <= 24) { if (norm == 1) launch_gram_xz<2, 1>(h, rot, chunks, cs); else launch_gram_xz<2, 2>(h, rot, chunks, cs); }
-  else { if (norm == 1) launch_gram_xz<3, 1>(h, rot, chunks, cs); else launch_gram_xz<3, 2>(h, rot, chunks, cs); }
+  if (norm == 1) gram_xz_m<1>(h, rot, chunks, cs);
+  else gram_xz_m<2>(h, rot, chunks, cs);
 }
 
 int depth_step_fused(mvsvd_handle *h, int method, double f0, double *E, double *timings) {
@@ -2010,7 +2036,8 @@ int depth_step_fused(mvsvd_handle *h, int method, double f0, double *E, double *
     MVBA_HIP(hipMemsetAsync(h->ddflag, 0, sizeof(int), st));
     const int mblocks = (int)std::max<long long>(1, std::min<long long>(512, (rows + GRAM_ROWS - 1) / GRAM_ROWS));  // two workgroups per CU
     const size_t mlds = sizeof(double) * (12 * (size_t)m + 4 * ((size_t)ROWS_PER_STEP * (n + m + 4) + 4 * ((size_t)ROWS_PER_STEP * (m | 1) + 8)));
-    hipLaunchKernelGGL(k_dual_gram_mfma, dim3(mblocks), dim3(256), mlds, st, dX, (const double *)dz, cs, h->dMr, is[0], is[1], is[2], is[3], rows, m, gpart);
+    auto dual_gram = m == 2 ? k_dual_gram_mfma<2> : (m == 4 ? k_dual_gram_mfma<4> : (m == 6 ? k_dual_gram_mfma<6> : (m == 8 ? k_dual_gram_mfma<8> : k_dual_gram_mfma<10>)));
+    hipLaunchKernelGGL(dual_gram, dim3(mblocks), dim3(256), mlds, st, dX, (const double *)dz, cs, h->dMr, is[0], is[1], is[2], is[3], rows, m, gpart);
     hipLaunchKernelGGL(k_dual_reduce_mfma, dim3((m * 90 + 3) / 4), dim3(256), 0, st, gpart, mblocks * 4, m, G12, colsum);
     hipLaunchKernelGGL(k_jacobi_small, dim3(m), dim3(JHB * JHB + JW * 6), 0, st, G12, V12, 12, 60, 1e-15, h->ddflag + 1);
     hipLaunchKernelGGL(k_dual_vec, dim3((m + 63) / 64), dim3(64), 0, st, G12, V12, colsum, m, w12, h->ddflag);
@@ -2078,10 +2105,9 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   for (const void *f : {(const void *)k_scale_rows_tiled<float>, (const void *)k_scale_rows_tiled<double>, (const void *)k_depth_primary<float, true>,
                         (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
-                        (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>, (const void *)k_primary_xz, (const void *)k_dual_gram_mfma,
-                        (const void *)k_dual_apply_xz, (const void *)k_gram_xz<1, 1, true>, (const void *)k_gram_xz<1, 2, true>, (const void *)k_gram_xz<2, 1, true>,
-                        (const void *)k_gram_xz<2, 2, true>, (const void *)k_gram_xz<3, 1, true>, (const void *)k_gram_xz<3, 2, true>, (const void *)k_gram_xz<3, 1, false>,
-                        (const void *)k_gram_xz<3, 2, false>})
+                        (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>, (const void *)k_primary_xz, (const void *)k_dual_gram_mfma<2>, (const void *)k_dual_gram_mfma<4>, (const void *)k_dual_gram_mfma<6>, (const void *)k_dual_gram_mfma<8>,
+                        (const void *)k_dual_gram_mfma<10>,
+                        (const void *)k_dual_apply_xz})
     SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX));
 #undef SVD_TRY
   *out = h;
