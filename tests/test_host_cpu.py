@@ -163,6 +163,49 @@ def test_bench_cpu_baseline_and_pmc_helpers(monkeypatch):
     assert len(bench.csrc_sha256()) == 64
 
 
+def test_bench_round5_helpers_cores_allreduce_model_and_shard_roofline(monkeypatch):
+    """bench.py's round-5 pieces on the CPU: the worker count follows what the box really grants (physical cores, affinity mask,
+    cgroup quota -- the GPU boxes of this pool grant 16 CPUs of 128 physical cores), the all-reduce model prices C1's bytes on the
+    xGMI links, and the Schur roofline object names what bounds each kernel form."""
+    import bench
+
+    assert bench.default_cpu_workers({"host_cpus": 256, "physical_cores": 128, "affinity_cpus": 256, "cgroup_quota_cpus": 16.0}) == 16
+    assert bench.default_cpu_workers({"host_cpus": 256, "physical_cores": 128, "affinity_cpus": 256, "cgroup_quota_cpus": None}) == 128
+    assert bench.default_cpu_workers({"host_cpus": 8, "physical_cores": None, "affinity_cpus": 4, "cgroup_quota_cpus": None}) == 4
+    assert bench.default_cpu_workers({"host_cpus": 512, "physical_cores": 256, "affinity_cpus": 512, "cgroup_quota_cpus": None}) == 128
+    info = bench.cpu_info()
+    assert info["host_cpus"] == os.cpu_count() and info["affinity_cpus"] >= 1 and (info["physical_cores"] or 1) >= 1
+    mdl = bench.allreduce_model(500, 8)
+    assert mdl["bytes_per_solve"] == 8 * (81 * 500 * 501 // 2 + 9 * 500) == 81_198_000
+    assert mdl["ring_one_link_ms"] == pytest.approx(2 * 7 / 8 * 81_198_000 / 153e9 * 1e3)
+    assert mdl["direct_all_links_ms"] == pytest.approx(2 * (81_198_000 / 8) / 153e9 * 1e3)
+    monkeypatch.setattr(bench, "pmc_traffic", lambda kernel, n_obs: (None, None))
+    unit = bench.schur_roofline({"kernel": "pairs", "items": 421_000_000, "offdiag_items": 390_000_000, "units": 1_000_000, "slot_rows": 0},
+                                31_246_709, 13.7, 256)
+    assert unit["bound"] == "fabric_line_fills" and unit["kernel"].startswith("k_schur_pairs")
+    assert unit["achieved"] == pytest.approx(192 * 31_246_709 / 13.7e-3 / 1e9) and unit["frac"] == pytest.approx(unit["achieved"] / 8000.0)
+    slot = bench.schur_roofline({"kernel": "slots", "items": 59_501_226, "offdiag_items": 49_499_384, "units": 47_600, "slot_rows": 66_863_118},
+                                10_001_842, 1.58, 256)
+    assert slot["bound"] == "l2_gather" and slot["gather"]["row_gathers_per_launch"] == 3 * 66_863_118
+
+
+def test_full_visibility_fast_paths_equal_the_general_ones():
+    """Round 5's host-side shortcuts for the all-visible case give exactly what the general code gives: the observation list of a
+    dense array without a mask (no np.nonzero / gather: 0.24 s at 1 M x 12) and the data matrix filled in place."""
+    from lib.bundle_adjustment import dense_to_observations
+    from lib.perspective_camera_calibration import _create_data_matrix
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((57, 6, 2))
+    a, b = dense_to_observations(x, None), dense_to_observations(x, np.ones((57, 6), bool))
+    for u, v in zip(a, b):
+        assert u.dtype == v.dtype and np.array_equal(u, v)
+    x_list = [x[:, k] for k in range(6)]
+    ref = np.stack([np.column_stack([xi / 1.7, np.ones(len(xi))]) for xi in x_list]).transpose(1, 0, 2)  # the reference's form (:34-40)
+    got = _create_data_matrix(x_list, 1.7)
+    assert got.flags["C_CONTIGUOUS"] and np.array_equal(got, ref)
+
+
 def test_bench_config1_leg_reproduces_the_reference_counts_on_the_cpu():
     """bench.py's config-1 leg: the dense-faithful oracle on the reference's default
     scene lands on 37 outer iterations / 59 solves / RMSE 0.0063291001035384233; without a GPU the
@@ -246,3 +289,5 @@ def test_slot_kernel_loops_carry_no_vector_memory_operation_the_counted_waits_do
     assert errs and any("overtake" in e for e in errs), errs
     errs = check_isa.check(text.replace(body, body.replace("s_barrier", "buffer_wbl2 sc1\n\ts_barrier", 1), 1))
     assert errs and any("device-wide fence" in e for e in errs), errs
+    errs = check_isa.check(text.replace(body, re.sub(r"(global_(?:load|store)_dwordx2[^\n]*?) sc1", r"\1", body), 1))
+    assert errs and any("no sc1 load / store" in e for e in errs), errs
