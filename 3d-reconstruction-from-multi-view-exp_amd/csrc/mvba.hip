@@ -684,8 +684,21 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
     return reinterpret_cast<const char *>(PB) + (((unsigned)a << 7) + ((unsigned)slot << 4));
   };
   // (OFFDIAG: 7 DMA instructions, DIAG: 6 -- and as many index loads per step: the slot form's counted wait relies on it)
-  auto issue = [&](char *buf, const int (&xk)[3], const int (&xl)[3], const int (&xa)[2]) {
+  auto issue = [&](char *buf, const int (&xk_)[3], const int (&xl_)[3], const int (&xa_)[2]) {
     char *kb = buf, *lb = buf + LB_OFF, *pb_ = buf + PB_OFF;
+#if defined(MVBA_KO_DMA)  // (timing-only knock-outs of the UNIT form, as for the slot form: no gathers / every row -> row 0 / the l side only / the point rows only)
+    (void)kb; (void)lb; (void)pb_; (void)xk_; (void)xl_; (void)xa_;
+    return;
+#endif
+#if defined(MVBA_KO_GATHER)
+    const int xk[3] = {0, 0, 0}, xl[3] = {0, 0, 0}, xa[2] = {0, 0};
+#elif defined(MVBA_KO_LSIDE)
+    const int xk[3] = {xk_[0], xk_[1], xk_[2]}, xl[3] = {0, 0, 0}, xa[2] = {xa_[0], xa_[1]};
+#elif defined(MVBA_KO_PROW)
+    const int xk[3] = {xk_[0], xk_[1], xk_[2]}, xl[3] = {xl_[0], xl_[1], xl_[2]}, xa[2] = {0, 0};
+#else
+    const int (&xk)[3] = xk_, (&xl)[3] = xl_, (&xa)[2] = xa_;
+#endif
     if (lane < 63) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {

@@ -158,7 +158,9 @@ def schur_roofline(info, n_obs, k3_ms, n_cu):
             "bound_note": ("not HBM: the CU's L2 -> LDS row gathers beside LDS reads and fp64 issue (see `gather`); `achieved` / `frac` price "
                            "SURVEY 8d's algorithmic 192 B/observation against the HBM peak as the contract asks" if slot_form else
                            "not HBM bandwidth on algorithmic bytes: the kernel's L2 misses (l-side records, half of the point rows) are line "
-                           "fills from the Infinity Cache / HBM at the chip's line-fill rate, `traffic` = 12-13 x the algorithmic bytes; "
+                           "fills from the Infinity Cache / HBM at the chip's line-fill rate, `traffic` = 12-13 x the algorithmic bytes -- the "
+                           "largest single named cost, yet only ~17 % of the launch (knock-out builds, profiles/r05_k3_knockouts.txt: 11.5 of "
+                           "13.9 ms remain with every gather hitting one line; the rest is a step's serial chain at 12 waves per CU); "
                            "`achieved` / `frac` price SURVEY 8d's 192 B/observation against the HBM peak as the contract asks"),
             "achieved": k3_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k3_ach / HBM_PEAK_GBS, "traffic": k3_traffic, "traffic_source": k3_src,

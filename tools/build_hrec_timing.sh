@@ -21,8 +21,19 @@ ko() {  # name define
   /opt/rocm/bin/hipcc $F -D$2 -c mvba.hip -o /tmp/mvba_$1.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/mvba_$1.o mvsvd.o -o ../../tools/ab2/libmvba_$1.so -ldl -lpthread
 }
+ko ko_gather MVBA_KO_GATHER &
+ko ko_dma MVBA_KO_DMA &
+ko ko_valu MVBA_KO_VALU &
+wait
+ko ko_valu_gather "MVBA_KO_VALU -DMVBA_KO_GATHER" &
+ko ko_valu_dma "MVBA_KO_VALU -DMVBA_KO_DMA" &
+ko hrec33_ko_gather "MVBA_HREC_TIMING -DMVBA_KO_GATHER" &
+wait
 ko ko_idx MVBA_KO_IDX &
 ko ko_idx_valu_dma "MVBA_KO_IDX -DMVBA_KO_VALU -DMVBA_KO_DMA" &
 ko ko_idx_dma "MVBA_KO_IDX -DMVBA_KO_DMA" &
 wait
-ls -la ../../tools/ab2
+# the same knock-outs for the UNIT form (config 4's shard: tools/ko_c4.sh): + the l side only, the point rows only
+ko ko_lside MVBA_KO_LSIDE &
+ko ko_prow MVBA_KO_PROW &
+wait
