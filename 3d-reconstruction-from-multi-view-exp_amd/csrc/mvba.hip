@@ -2884,6 +2884,8 @@ struct mvba_handle {
   bool slot_pace = true;
   int slot_lag = 4;                   // a wave enters segment j only when all waves of its range have left segment j - lag
   int *d_seg_end = nullptr, *d_prog = nullptr;
+  bool check_solve = false;           // MVBA_CHECK_SOLVE=1: every accepted dense solve is checked on the host against the packed system it solved
+  double check_solve_tol = 1e-8;      // (MVBA_CHECK_SOLVE=<t> with 0 < t < 1: that tolerance -- the tests ask for an impossible one to see the check fire)
   bool gcam = false;                  // more than LDS_CAMERAS cameras: the kernels read the camera tables from device memory (d_cam18, d_dxi10)
   double *d_cam18 = nullptr, *d_dxi10 = nullptr;
   bool index_on_device = false;       // the Schur index was built by the k_idx_* kernels (nothing to upload)
@@ -3296,6 +3298,11 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (const char *ev = getenv("MVBA_PAIR_STATIC")) h->pair_static = atoi(ev) != 0;
   if (const char *ev = getenv("MVBA_BACKSUB_LANES")) h->backsub_lanes = atoi(ev);
   h->force_big = getenv("MVBA_FORCE_BIG") != nullptr;
+  if (const char *ev = getenv("MVBA_CHECK_SOLVE")) {
+    const double v = atof(ev);
+    h->check_solve = v != 0.0;
+    if (v > 0.0 && v < 1.0) h->check_solve_tol = v;
+  }
   if (m > 65535) h->schur_mode = SCHUR_STRIP;
   h->use_pairs = h->schur_mode != SCHUR_STRIP;
   std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units, st_k, st_l, st_a, wunits, seg_end;
@@ -4367,6 +4374,38 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream);
     if (fl & 8) return fail(MVBA_ERR_HIP, "k_chol_backsolve_all: a device-wide barrier timed out twice (is another process holding the CUs?)");
     return fail(MVBA_ERR_SINGULAR, (fl & 1) ? "Singular matrix" : "Singular matrix (reduced camera system)");
+  }
+  if (h->check_solve) {
+    // Debug mode (MVBA_CHECK_SOLVE=1, read in mvba_create): the residual of the reduced system, b - A dxi over the kept parameters,
+    // from the packed [A|b] the solve started from (it is intact: k_compact copied it) and the dxi it produced -- on the host, in
+    // plain loops.  The persistent back-substitution orders its hand-overs with sc1 accesses and explicit waits, not with the
+    // memory model's fences: a stale read there would be a silently wrong camera step, which this catches.
+    std::vector<double> Ab(nA + n9), x(n9);
+    MVBA_HIP(hipMemcpyAsync(Ab.data(), h->d_Ab, sizeof(double) * (nA + n9), hipMemcpyDeviceToHost, h->stream));
+    MVBA_HIP(hipMemcpyAsync(x.data(), h->d_dxi, sizeof(double) * n9, hipMemcpyDeviceToHost, h->stream));
+    MVBA_HIP(hipStreamSynchronize(h->stream));
+    auto kept = [&](size_t g) { return !((g >= 3 && g <= 8) || g == (size_t)(12 + h->gauge_axis)); };
+    std::vector<double> r(n9, 0.0), an(n9, 0.0);  // r = A x, an = |A| |x|  (rows of the full symmetric matrix from the packed upper strips)
+    for (int k = 0; k < m; ++k) {
+      const double *Ak = Ab.data() + strip_offset(k, m);
+      const int Wk = 9 * (m - k);
+      for (int i = 0; i < 9; ++i)
+        for (int c = 0; c < Wk; ++c) {
+          const size_t gi = 9 * (size_t)k + i, gj = 9 * (size_t)k + c;
+          const double a = Ak[(size_t)i * Wk + c];
+          r[gi] += a * x[gj]; an[gi] += std::fabs(a * x[gj]);
+          if (c >= 9) { r[gj] += a * x[gi]; an[gj] += std::fabs(a * x[gi]); }  // the mirror image below the diagonal blocks
+        }
+    }
+    double worst = 0.0;
+    for (size_t g = 0; g < n9; ++g)
+      if (kept(g)) {
+        const double bg = Ab[nA + g], scale = an[g] + std::fabs(bg);
+        worst = std::max(worst, scale > 0.0 ? std::fabs(bg - r[g]) / scale : 0.0);
+      }
+    if (!(worst <= h->check_solve_tol))
+      return fail(MVBA_ERR_STATE, "MVBA_CHECK_SOLVE: the dense solve left a relative residual of " + std::to_string(worst) +
+                                      " on the reduced camera system (a stale hand-over in the back-substitution?)");
   }
   h->have_trial = true;
   return MVBA_OK;

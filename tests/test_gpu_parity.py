@@ -524,6 +524,29 @@ def test_repeated_dense_solves_are_bitwise_identical():
     assert counts["barrier_fallback"] == 0 and counts["lu_fallback"] == 0
 
 
+@pytest.mark.parametrize("n,m,p,chol", [(4000, 30, 0.3, None), (20000, 120, 0.1, None), (3000, 300, 0.06, None), (3000, 300, 0.06, "barriers"),
+                                         (3000, 300, 0.06, "launches")])
+def test_dense_solve_residual_check_passes_on_every_back_substitution_variant(n, m, p, chol, monkeypatch):
+    """MVBA_CHECK_SOLVE=1 (debug mode): after every dense solve the residual b - A dxi of the reduced camera system is formed on the
+    host from the packed [A|b] and must be at rounding level -- here over LM runs at one and several super-blocks (D = 263 / 1073 /
+    2693) and on the three back-substitution variants (point-to-point hand-overs, device-wide barriers, one launch per super-block)."""
+    from lib.bundle_adjustment import lm_loop
+
+    monkeypatch.setenv("MVBA_CHECK_SOLVE", "1")
+    if chol:
+        monkeypatch.setenv("MVBA_CHOL", chol)
+    sc = make_scene(n, m, vis_p=p)
+    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t, axis=sc.axis)
+    E = lm_loop(ba._engine, 2.0, -1.0, 4, verbose=False)
+    assert np.isfinite(E) and ba._engine.stats()["counts"]["lu_fallback"] == 0
+    if chol is None and m == 30:  # the check is not vacuous: an impossible tolerance makes it fire, with the residual in the message
+        monkeypatch.setenv("MVBA_CHECK_SOLVE", "1e-30")
+        ba2 = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t, axis=sc.axis)
+        ba2._engine.linearize()
+        with pytest.raises(RuntimeError, match="relative residual"):
+            ba2._engine.try_step(1e-4)
+
+
 def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_launches(monkeypatch):
     """k_chol_backsolve_all's waits (on its progress words; device-wide barriers in the MVBA_CHOL=barriers form) give up
     after a bounded number of polls (a grid that is not co-resident -- another process on the CUs -- must drain, not hang).
