@@ -392,6 +392,255 @@ __global__ __launch_bounds__(256) void k_rotate_rows(const T *__restrict__ Wt, l
   }
 }
 
+// ------------------------------------------------------------------ wide matrices (n > WIDE_MIN columns)
+// The n x n eigenproblem of the Gram route runs in ONE workgroup: 0.4 s at n = 256, 3.3 s at 512, minutes beyond -- and its
+// projection staged 5 n doubles in LDS, so that n >= ~900 did not launch at all (round 5, tools/time_svd_wide.py).  The
+// callers only ever keep r <= 4 triplets (ref lib/factorization.py:10-15), so beyond WIDE_MIN columns (and up to 16 triplets) the leading subspace is
+// found by block power iteration with Rayleigh-Ritz on W^T W applied IMPLICITLY, WB = 32 vectors wide, two passes over W per
+// iteration and no n x n matrix anywhere:
+//   B = (W - mu) Q           k_wq    (N x WB, f64 matrix cores, W staged through LDS in 64 x 64 tiles)
+//   H = B^T B = Q^T W^T W Q  the fused small Gram kernel on B; Jacobi (k_jacobi_small) -> theta, Y
+//   Z = (W - mu)^T (B Y)     k_rotate_rows on B, then k_wtb (n x WB, partial sums per row chunk, fixed-order reduction)
+//   Q <- Q Y                 k_ritz  (Ritz vectors; residuals ||z_j - theta_j q_j||)
+//   Q <- orth(Z)             Gram of Z (n x WB), Cholesky-QR in Ritz order (k_chol_orth + k_rotate_rows), twice
+// Convergence factor per iteration (sigma_33 / sigma_r)^2; a measurement matrix (rank 3-4 + noise) converges in 3-6 iterations.
+// The products are formed from W itself, never from an accumulated Gram matrix, and the basis is kept GRADED (Ritz order,
+// triangular orthogonalisation), so a small sigma_r keeps the accuracy of the two-pass form (rounding ~ eps sigma_1 sigma_r, not
+// eps sigma_1^2).  At the end B = (W - mu) Q once more: its Gram matrix is nearly diagonal and graded, a last Jacobi gives
+// sigma = sqrt(theta) and the final rotation, S is B's leading columns (S = M^T W by construction: no projection pass).
+// sigma[WB..] is not computed (NaN).
+constexpr int WIDE_MIN = 64;     // columns above which the implicit form takes over (n <= 64: the eigenproblem sits in LDS, 6 ms)
+constexpr int JACOBI_MAX = 256;  // columns up to which the Gram + Jacobi route stays available (n_rank > 16: 0.4 s of Jacobi there)
+constexpr int MVSVD_MAX_COLS = 3 * 4096;  // three rows of W per image at MAX_CAMERAS of the bundle-adjustment engine
+constexpr int WB = 32;       // block width (= the small solver's order)
+constexpr int WT = 64;       // tile edge of the two products
+
+// B[row][j] = sum_c (Wt[row][c] - mu[c]) Q[c][j], j < WB.  One workgroup per 64 rows, wave w its rows 16 w .. 16 w + 15.
+template <typename T>
+__global__ __launch_bounds__(256) void k_wq(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
+                                            const double *__restrict__ Q, double *__restrict__ B) {
+  __shared__ double sW[WT][WT + 1], sQ[WT][WB + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const long long r0 = (long long)blockIdx.x * WT;
+  svd_d4 acc[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  for (int c0 = 0; c0 < n; c0 += WT) {
+    for (int e = threadIdx.x; e < WT * WT; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const long long row = r0 + r;
+      sW[r][c] = (row < n_rows && c0 + c < n) ? (double)Wt[row * n + c0 + c] - (mu ? mu[c0 + c] : 0.0) : 0.0;
+    }
+    for (int e = threadIdx.x; e < WT * WB; e += 256) {
+      const int k = e >> 5, j = e & 31;
+      sQ[k][j] = (c0 + k < n) ? Q[(size_t)(c0 + k) * WB + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < WT / 4; ++kk) {
+      const double a = sW[16 * wave + li][4 * kk + lk];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[4 * kk + lk][li], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[4 * kk + lk][16 + li], acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long row = r0 + 16 * wave + lk + 4 * q;
+    if (row < n_rows) {
+      B[row * WB + li] = acc[0][q];
+      B[row * WB + 16 + li] = acc[1][q];
+    }
+  }
+}
+
+// zpart[chunk][c][j] = sum over the chunk's rows of (Wt[row][c] - mu[c]) B[row][j].  blockIdx.x = 64 columns of W (wave w its
+// columns 16 w ..), blockIdx.y = row chunk (rows_per_chunk, a multiple of 64).
+template <typename T>
+__global__ __launch_bounds__(256) void k_wtb(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
+                                             const double *__restrict__ B, long long rows_per_chunk, double *__restrict__ zpart) {
+  __shared__ double sW[WT][WT + 1], sB[WT][WB + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int c0 = blockIdx.x * WT;
+  const long long rb = (long long)blockIdx.y * rows_per_chunk, re = min(n_rows, rb + rows_per_chunk);
+  svd_d4 acc[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  for (long long r0 = rb; r0 < re; r0 += WT) {
+    for (int e = threadIdx.x; e < WT * WT; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const long long row = r0 + r;
+      sW[r][c] = (row < re && c0 + c < n) ? (double)Wt[row * n + c0 + c] - (mu ? mu[c0 + c] : 0.0) : 0.0;
+    }
+    for (int e = threadIdx.x; e < WT * WB; e += 256) {
+      const int r = e >> 5, j = e & 31;
+      sB[r][j] = (r0 + r < re) ? B[(r0 + r) * WB + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < WT / 4; ++kk) {
+      const double a = sW[4 * kk + lk][16 * wave + li];  // A[i][k] = W[row k][column i]
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[4 * kk + lk][li], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[4 * kk + lk][16 + li], acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double *out = zpart + (size_t)blockIdx.y * n * WB;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + 16 * wave + lk + 4 * q;
+    if (c < n) {
+      out[(size_t)c * WB + li] = acc[0][q];
+      out[(size_t)c * WB + 16 + li] = acc[1][q];
+    }
+  }
+}
+
+// out[e] = sum over the chunks, in order, of part[chunk][e]
+__global__ void k_sum_chunks(const double *__restrict__ part, int chunks, long long count, double *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * count + e];
+  out[e] = s;
+}
+
+// Q[n][WB]: a fixed pseudo-random start (the same for every call: the result must not depend on a seed the caller cannot see)
+__device__ __forceinline__ double wide_hash(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return (double)(long long)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0;  // [-1, 1)
+}
+__global__ void k_wide_init(double *__restrict__ Q, int n, unsigned long long salt) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long long)n * WB) Q[e] = wide_hash((unsigned long long)e * 0x9e3779b97f4a7c15ull + salt);
+}
+
+// Ritz rotation of the basis, one thread per row: q <- q Y (Y = eigenvectors of H; `Hr` = Y^T H Y as the small solver leaves it:
+// theta on the diagonal, whatever it did not rotate away beside it), and the residual partials
+// respart[block][j] = sum_rows (z_j - sum_i q_i Hr_ij)^2 against Z = W^T (B Y), which the caller formed from the ROTATED product.
+//  * Rotating Z itself -- z <- z Y -- forms a vector of length sigma_4^2 as a combination of vectors of length sigma_1^2: a
+//    sigma_4 = 1e-7 sigma_1 then comes out with 1e-16 / 1e-14 of relative noise, most of it outside the row space of W, and the
+//    block loses that direction to 2e-3 (found with a NumPy restatement of the iteration).  B Y loses 1e-16 / 1e-7 and W^T maps
+//    whatever it is given into the row space.
+//  * The residual is taken against the WHOLE row of Hr, not theta_j alone: the solver leaves |Hr_1j| up to 4.5e-16 theta_1 (its
+//    absolute floor), i.e. q_j keeps 1e-16 of q_1 -- harmless for q_j, but theta_1 times it is 1e-2 of a theta_j = 1e-14 theta_1
+//    and would sit in the plain residual for ever.  Projected (the Galerkin condition, numerically), what is left is the part of
+//    W^T W q_j OUTSIDE the block: the quantity the next iteration can still improve.
+// Z == nullptr: the rotation alone.
+__global__ __launch_bounds__(256) void k_ritz(double *__restrict__ Q, const double *__restrict__ Z, int n, const double *__restrict__ Y,
+                                              const double *__restrict__ Hr, double *__restrict__ respart) {
+  __shared__ double sY[WB][WB], sH[WB][WB], sred[4][WB];
+  for (int e = threadIdx.x; e < WB * WB; e += 256) { sY[e >> 5][e & 31] = Y[e]; sH[e >> 5][e & 31] = Hr[e]; }
+  __syncthreads();
+  const int row = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool ok = row < n;
+  double q[WB];
+#pragma unroll
+  for (int k = 0; k < WB; ++k) q[k] = ok ? Q[(size_t)row * WB + k] : 0.0;
+#pragma unroll 1
+  for (int j = 0; j < WB; ++j) {
+    double qj = 0.0;
+#pragma unroll
+    for (int k = 0; k < WB; ++k) qj = fma(q[k], sY[k][j], qj);
+    if (ok) Q[(size_t)row * WB + j] = qj;
+  }
+  if (!Z || !respart) return;  // (uniform)
+#pragma unroll
+  for (int k = 0; k < WB; ++k) q[k] = ok ? Q[(size_t)row * WB + k] : 0.0;  // the rotated row (this thread's own stores)
+#pragma unroll 1
+  for (int j = 0; j < WB; ++j) {
+    double zp = 0.0;
+#pragma unroll
+    for (int k = 0; k < WB; ++k) zp = fma(q[k], sH[k][j], zp);
+    double d = (ok ? Z[(size_t)row * WB + j] : 0.0) - zp;
+    d *= d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+    if (lane == 0) sred[wave][j] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < WB) respart[(size_t)blockIdx.x * WB + threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
+// Orthonormalisation step: Cholesky-QR in Ritz order.  The columns of Z differ in length by (sigma_1 / sigma_32)^2, so C = Z^T Z
+// is brought to unit diagonal (d_j = C_jj^-1/2: its entries are then accurate to eps whatever the columns' lengths), its rows and
+// columns are put in the order of DESCENDING Ritz value (`Hd`: the diagonal the small solver left in H; nullptr: as they are), and
+// P^T D C D P = L L^T.  Q = Z D P L^-T then has orthonormal columns, sorted by Ritz value, and column r only mixes the columns of
+// rank <= r -- a small triplet's vector is cleaned of the large ones and never the other way round, so the basis stays graded
+// and the next Rayleigh-Ritz step keeps the small triplets' relative accuracy.  (A symmetric orthogonalisation -- eigenvectors of C --
+// mixes every column with the 28 noise columns at the 1 / sqrt(n) level: B^T B was then no longer graded, a sigma_4 = 1e-7 sigma_1
+// came out of the Ritz step to 1e-2 only, and the residual test stalled there.)  A pivot below 1e-12 -- the column depends on
+// its predecessors to 1e-6: the block has lost rank, W has fewer than WB independent rows / columns, or a column of Z is exactly
+// zero -- gives a zero column and flag[r] = 1; k_wide_refill then puts a pseudo-random column in its place before the second pass.
+// One wave; lane i owns row i of the factor.
+__global__ __launch_bounds__(64) void k_chol_orth(const double *__restrict__ C, const double *__restrict__ Hd, double *__restrict__ Tm,
+                                                  int *__restrict__ flag) {
+  __shared__ double A[WB][WB + 1], Li[WB][WB + 1], sd[WB], sth[WB];
+  __shared__ int perm[WB], dead[WB];
+  const int lane = threadIdx.x;
+  if (lane < WB) {
+    const double c = C[lane * WB + lane];
+    sd[lane] = c > 0.0 ? 1.0 / sqrt(c) : 0.0;
+    sth[lane] = Hd ? Hd[lane * WB + lane] : 0.0;
+  }
+  __syncthreads();
+  if (lane < WB) {  // rank of this column by Ritz value (ties: by index)
+    int r = 0;
+    for (int k = 0; k < WB; ++k) r += (sth[k] > sth[lane]) || (sth[k] == sth[lane] && k < lane);
+    perm[Hd ? r : lane] = lane;
+  }
+  __syncthreads();
+  for (int e = lane; e < WB * WB; e += 64) {
+    const int i = e >> 5, j = e & 31, pi = perm[i], pj = perm[j];
+    A[i][j] = i == j ? (sd[pi] > 0.0 ? 1.0 : 0.0) : C[pi * WB + pj] * sd[pi] * sd[pj];
+    Li[i][j] = 0.0;
+  }
+  __syncthreads();
+  // right-looking Cholesky, the factor overwrites the lower triangle of A
+  for (int j = 0; j < WB; ++j) {
+    if (lane == j) {
+      const double piv = A[j][j];
+      dead[j] = !(piv > 1e-12);
+      A[j][j] = dead[j] ? 1.0 : sqrt(piv);
+    }
+    __syncthreads();
+    const bool dj = dead[j] != 0;
+    if (lane > j && lane < WB) A[lane][j] = dj ? 0.0 : A[lane][j] / A[j][j];
+    __syncthreads();
+    if (lane > j && lane < WB && !dj) {
+      const double lij = A[lane][j];
+      for (int k = j + 1; k <= lane; ++k) A[lane][k] -= lij * A[k][j];
+    }
+    __syncthreads();
+  }
+  // L^-1 by forward substitution, lane c its column c
+  if (lane < WB) {
+    const int c = lane;
+    for (int i = c; i < WB; ++i) {
+      double v = i == c ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) v -= A[i][k] * Li[k][c];
+      Li[i][c] = v / A[i][i];
+    }
+  }
+  __syncthreads();
+  // T[p_i][r] = d_{p_i} (L^-1)[r][i], i <= r
+  for (int e = lane; e < WB * WB; e += 64) {
+    const int i = e >> 5, r = e & 31;
+    Tm[perm[i] * WB + r] = (i <= r && !dead[r]) ? sd[perm[i]] * Li[r][i] : 0.0;
+  }
+  if (lane < WB) flag[lane] = dead[lane];
+}
+__global__ void k_wide_refill(double *__restrict__ Q, int n, const int *__restrict__ flag, unsigned long long salt) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)n * WB) return;
+  const int j = (int)(e & (WB - 1));
+  if (flag[j]) Q[e] = wide_hash((unsigned long long)e * 0x9e3779b97f4a7c15ull + salt) * rsqrt((double)n / 3.0);  // ~unit length
+}
+
+// S[i][row] = sgn[i] B[row][col[i]] (the workspace's dtype): the leading columns of the rotated B ARE M^T (W - mu)
+template <typename T>
+__global__ void k_take_cols(const double *__restrict__ B, long long n_rows, int r, const int *__restrict__ col, const double *__restrict__ sgn, T *__restrict__ S) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  for (int i = 0; i < r; ++i) S[(size_t)i * n_rows + row] = (T)(sgn[i] * B[row * WB + col[i]]);
+}
+
 // Round-robin parallel Jacobi on the symmetric n x n matrix A (global memory), eigenvectors in V.
 // np = n rounded up to even (a phantom index np-1 == n is skipped).
 template <bool IN_LDS>  // IN_LDS: both n x n matrices live in LDS (n <= 64): latency ~100 ns instead of ~1.5 us
@@ -1684,42 +1933,52 @@ struct mvsvd_handle {
   double *ddep = nullptr;             // depth iteration: error partials, 12 x 12 problems, vectors (one allocation)
   int *ddflag = nullptr;
   int chunks = 1, rank_cap = 0;
+  // wide path (n > WIDE_MIN): bases Q, Z [n][WB], products B, B2 [max_rows][WB] (dBw / dB2), row-chunk partials of Z, small problems
+  double *dQ = nullptr, *dZ = nullptr, *dQ2 = nullptr, *dBw = nullptr, *dB2 = nullptr, *dzpart = nullptr, *dsmall = nullptr;
+  int *dwflag = nullptr;
+  int zchunks = 1, wide_iters = 0;
+  long long zrows_per_chunk = 0;
   double h2d_ms = 0.0;
   bool loaded = false;
 };
 
 namespace {
 
+// G = (W - mu)^T (W - mu) of an n_rows x n matrix through the workspace's partial buffers (the workspace's own matrix, or -- the
+// wide path -- one of its n x 32 / N x 32 blocks)
 template <typename T>
-void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) {
-  const int n = h->n, n_tiles = (n + GT - 1) / GT;
+void launch_gram_n(mvsvd_handle *h, const T *W, long long n_rows, int n, const double *mu, int chunks, double *G) {
+  const int n_tiles = (n + GT - 1) / GT;
   const bool packed = n > 16 && n <= 24;
   const int n_pairs = packed ? 2 : n_tiles * (n_tiles + 1) / 2;
   if (n <= 16)
-    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 1 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 1>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 1 * 8192), h->st, W, n_rows, n, mu, h->dpart);
   else if (packed)
-    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 2 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 2>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 2 * 8192), h->st, W, n_rows, n, mu, h->dpart);
   else if (n <= 32)
-    hipLaunchKernelGGL((k_gram_fused<T, 3>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 3 * 8192), h->st, W, h->n_rows, n, mu, h->dpart);
+    hipLaunchKernelGGL((k_gram_fused<T, 3>), dim3(1, chunks), dim3(256), std::max<size_t>(sizeof(T) * GRAM_ROWS * n, 3 * 8192), h->st, W, n_rows, n, mu, h->dpart);
   else
-    hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, h->st, W, h->n_rows, n, n_tiles, n_pairs, mu, h->dpart);
+    hipLaunchKernelGGL(k_gram_pair<T>, dim3(n_pairs, chunks), dim3(256), 0, h->st, W, n_rows, n, n_tiles, n_pairs, mu, h->dpart);
   const int slices = std::min(chunks, GRAM_SLICES);
   hipLaunchKernelGGL(k_gram_reduce, dim3(n_pairs, slices), dim3(256), 0, h->st, h->dpart, chunks, n_pairs, h->dpart2);
-  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dpart2, slices, n_pairs, n_tiles, packed ? 1 : 0, h->dG, n);
+  hipLaunchKernelGGL(k_gram_finish, dim3((n + 127) / 128, n), dim3(128), 0, h->st, h->dpart2, slices, n_pairs, n_tiles, packed ? 1 : 0, G, n);
 }
+template <typename T>
+void launch_gram(mvsvd_handle *h, const T *W, const double *mu, int chunks) { launch_gram_n<T>(h, W, h->n_rows, h->n, mu, chunks, h->dG); }
 
 // tol: rotate while |a_pq| > tol sqrt(|a_pp a_qq|).  1e-15 for float64 input; float32 input carries
 // 6e-8 of relative noise per entry, so its Gram matrix is diagonalised to 1e-11 (one or two sweeps fewer).
-void launch_jacobi(mvsvd_handle *h, double *dVout, double tol) {
-  const int n = h->n, np = (n + 1) & ~1;
+void launch_jacobi_n(mvsvd_handle *h, double *dA, int n, double *dVout, double tol) {
+  const int np = (n + 1) & ~1;
   const size_t nn = (size_t)n * n, jl = sizeof(double) * (3 * (np / 2) + 2) + 16;
   if (n <= JW)
-    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(JHB * JHB + JW * (np / 2)), 0, h->st, h->dG, dVout, n, 60, tol, h->dsw);  // (A blocks + V pieces)
+    hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(JHB * JHB + JW * (np / 2)), 0, h->st, dA, dVout, n, 60, tol, h->dsw);  // (A blocks + V pieces)
   else if (n <= 64)
-    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, h->dG, dVout, n, 60, tol, h->dsw);
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(256), jl + sizeof(double) * 2 * nn, h->st, dA, dVout, n, 60, tol, h->dsw);
   else
-    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, h->st, h->dG, dVout, n, 60, tol, h->dsw);
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), jl, h->st, dA, dVout, n, 60, tol, h->dsw);
 }
+void launch_jacobi(mvsvd_handle *h, double *dVout, double tol) { launch_jacobi_n(h, h->dG, h->n, dVout, tol); }
 
 int chunks_for(long long n_rows, int n) {
   const int n_tiles = (n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -1728,7 +1987,11 @@ int chunks_for(long long n_rows, int n) {
 }
 
 template <typename T>
+int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means, double *timings);
+
+template <typename T>
 int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means, double *timings) {
+  if (h->n > WIDE_MIN && (n_rank <= WB / 2 || h->n > JACOBI_MAX)) return run_wide<T>(h, n_rank, center, M, sigma, S, means, timings);
   const int n = h->n;
   const long long n_rows = h->n_rows;
   const size_t nn = (size_t)n * n;
@@ -1828,6 +2091,153 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
 }  // namespace
 
 namespace {
+
+// The factorisation of a wide matrix (n > WIDE_MIN columns): block power iteration with Rayleigh-Ritz, see the kernels' header.
+template <typename T>
+int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means, double *timings) {
+  const int n = h->n;
+  const long long N = h->n_rows;
+  hipStream_t st = h->st;
+  const T *dW = (const T *)h->dW;
+  if (n_rank > WB / 2)
+    return fail(MVBA_ERR_BADARG, "n_cols > " + std::to_string(JACOBI_MAX) + ": the block iteration carries " + std::to_string(WB) + " vectors, n_rank <= " + std::to_string(WB / 2));
+  hipEventRecord(h->ev[1], st);
+  const double *mu = nullptr;
+  if (center) {
+    const int cy = (int)std::max<long long>(1, std::min<long long>(COLSUM_SLICES, N / 4096));
+    hipLaunchKernelGGL(k_colsum<T>, dim3(n, cy), dim3(256), 0, st, dW, N, n, h->dsum);
+    hipLaunchKernelGGL(k_mean_from_sum, dim3((n + 255) / 256), dim3(256), 0, st, h->dsum, cy, n, N, h->dmu);
+    mu = h->dmu;
+  }
+  hipEventRecord(h->ev[2], st);
+  double *H = h->dsmall, *Y = H + WB * WB, *C = Y + WB * WB, *V = C + WB * WB, *Tm = V + WB * WB, *dres = Tm + WB * WB, *respart = dres + WB;
+  int *dcol = h->dwflag + WB;                      // [WB] columns to take at the end
+  double *dsgn = respart + (size_t)WB * ((n + 255) / 256);  // [WB] their signs
+  const int chunksB = chunks_for(N, WB), chunksZ = chunks_for(n, WB);
+  const int wgrid = (int)((N + WT - 1) / WT), ngrid = (int)(((long long)n * WB + 255) / 256), rgrid = (n + 255) / 256;
+  const int rot_grid_n = (int)std::max<long long>(1, std::min<long long>(6 * 256, (n + GRAM_ROWS - 1) / GRAM_ROWS));
+  const size_t rot_lds = (size_t)GRAM_ROWS * WB * sizeof(double);
+  const int bgrid = (int)std::max<long long>(1, std::min<long long>(6 * 256, (N + GRAM_ROWS - 1) / GRAM_ROWS));
+  auto orth = [&](double *src, double *tmp, double *dst, const double *ritz, unsigned long long salt) {  // dst <- orthonormal basis of span(src), in Ritz order; src and tmp are scratch
+    launch_gram_n<double>(h, src, n, WB, nullptr, chunksZ, C);
+    hipLaunchKernelGGL(k_chol_orth, dim3(1), dim3(64), 0, st, C, ritz, Tm, h->dwflag);
+    hipLaunchKernelGGL(k_rotate_rows<double>, dim3(rot_grid_n), dim3(256), rot_lds, st, src, (long long)n, WB, (const double *)nullptr, Tm, tmp);
+    hipLaunchKernelGGL(k_wide_refill, dim3(ngrid), dim3(256), 0, st, tmp, n, h->dwflag, salt);
+    launch_gram_n<double>(h, tmp, n, WB, nullptr, chunksZ, C);
+    hipLaunchKernelGGL(k_chol_orth, dim3(1), dim3(64), 0, st, C, (const double *)nullptr, Tm, h->dwflag);
+    hipLaunchKernelGGL(k_rotate_rows<double>, dim3(rot_grid_n), dim3(256), rot_lds, st, tmp, (long long)n, WB, (const double *)nullptr, Tm, dst);
+  };
+  auto product_b = [&](const double *Q) {  // B = (W - mu) Q, H = B^T B, Jacobi: theta on H's diagonal, Y
+    hipLaunchKernelGGL(k_wq<T>, dim3(wgrid), dim3(256), 0, st, dW, N, n, mu, Q, h->dBw);
+    launch_gram_n<double>(h, h->dBw, N, WB, nullptr, chunksB, H);
+    launch_jacobi_n(h, H, WB, Y, 1e-15);
+  };
+  // start: a fixed pseudo-random block, orthonormalised
+  hipLaunchKernelGGL(k_wide_init, dim3(ngrid), dim3(256), 0, st, h->dZ, n, 0x5eedull);
+  orth(h->dZ, h->dQ2, h->dQ, nullptr, 1);
+  double theta[WB], res[WB];
+  const int max_iter = 2000;
+  int it = 0;
+  // Residuals of the leading n_rank Ritz pairs (k_ritz: the part of W^T W q_j outside the block): `worst` relative to theta_1 (what
+  // the leading triplets need: <= 1e-13, or at this matrix's rounding floor -- no halving over three iterations -- below 1e-10)
+  // and `rel`, each against its own pair's scale max(1e-12 theta_j, 50 eps sqrt(theta_1 theta_j)): the angle of a SMALL
+  // triplet's vector is r_j / theta_j (a sigma_4 = 1e-7 sigma_1 is invisible at the 1e-13 theta_1 level), and
+  // eps sigma_1 / sigma_j is what the products W q, W^T b leave of it.
+  double worst = 0.0, rel = 0.0, best = 1e300, best_rel = 1e300;
+  int stalled = 0, stalled_rel = 0;
+  bool converged = false;
+  for (; it < max_iter; ++it) {
+    product_b(h->dQ);
+    hipLaunchKernelGGL(k_rotate_rows<double>, dim3(bgrid), dim3(256), rot_lds, st, h->dBw, N, WB, (const double *)nullptr, Y, h->dB2);  // B Y = W (Q Y)
+    hipLaunchKernelGGL(k_wtb<T>, dim3((n + WT - 1) / WT, h->zchunks), dim3(256), 0, st, dW, N, n, mu, h->dB2, h->zrows_per_chunk, h->dzpart);
+    hipLaunchKernelGGL(k_sum_chunks, dim3(ngrid), dim3(256), 0, st, h->dzpart, h->zchunks, (long long)n * WB, h->dZ);
+    hipLaunchKernelGGL(k_ritz, dim3(rgrid), dim3(256), 0, st, h->dQ, (const double *)h->dZ, n, Y, H, respart);
+    hipLaunchKernelGGL(k_sum_chunks, dim3(1), dim3(256), 0, st, respart, rgrid, (long long)WB, dres);
+    std::vector<double> hH((size_t)WB * WB);
+    MVBA_HIP(hipMemcpyAsync(hH.data(), H, sizeof(double) * WB * WB, hipMemcpyDeviceToHost, st));
+    MVBA_HIP(hipMemcpyAsync(res, dres, sizeof(double) * WB, hipMemcpyDeviceToHost, st));
+    MVBA_HIP(hipStreamSynchronize(st));
+    for (int j = 0; j < WB; ++j) theta[j] = hH[(size_t)j * WB + j];
+    int order[WB];
+    std::iota(order, order + WB, 0);
+    std::sort(order, order + WB, [&](int a, int b) { return theta[a] > theta[b]; });
+    const double tmax = std::max(theta[order[0]], 0.0);
+    worst = rel = 0.0;
+    for (int i = 0; i < n_rank; ++i) {
+      const double rj = std::sqrt(std::max(res[order[i]], 0.0)), tj = theta[order[i]];
+      worst = std::max(worst, rj);
+      if (tj > 1e-28 * tmax) rel = std::max(rel, rj / std::max(1e-12 * tj, 1.1e-14 * std::sqrt(tmax * tj)));  // (sigma_j below 1e-14 sigma_1 is numerically zero: the absolute measure covers it)
+    }
+    worst = tmax > 0.0 ? worst / tmax : 0.0;
+    if (!(worst == worst) || !(rel == rel)) return fail(MVBA_ERR_SINGULAR, "SVD did not converge (non-finite values in the measurement matrix)");
+    if (worst < 0.5 * best) { best = worst; stalled = 0; } else ++stalled;
+    if (rel < 0.5 * best_rel) { best_rel = rel; stalled_rel = 0; } else ++stalled_rel;
+    const bool done_abs = worst <= 1e-13 || (stalled >= 3 && worst <= 1e-10), done_rel = rel <= 1.0 || stalled_rel >= 3;
+    if (done_abs && done_rel) { converged = true; ++it; break; }
+    orth(h->dZ, h->dQ2, h->dQ, H, 2 + (unsigned long long)it);
+  }
+  h->wide_iters = it;
+  if (!converged)
+    return fail(MVBA_ERR_SINGULAR, "SVD did not converge: block power iteration, residual " + std::to_string(worst) + " of sigma_1^2 after " + std::to_string(it) +
+                                       " iterations (singular values " + std::to_string(n_rank) + " .. " + std::to_string(WB) + " of this matrix are too close)");
+  hipEventRecord(h->ev[3], st);
+  // final pass: Q holds the Ritz vectors; B = (W - mu) Q has a nearly diagonal, graded Gram matrix -> sigma and the last rotation
+  product_b(h->dQ);
+  hipLaunchKernelGGL(k_ritz, dim3(rgrid), dim3(256), 0, st, h->dQ, (const double *)nullptr, n, Y, H, (double *)nullptr);
+  hipLaunchKernelGGL(k_rotate_rows<double>, dim3(bgrid), dim3(256), rot_lds, st, h->dBw, N, WB, (const double *)nullptr, Y, h->dB2);
+  std::vector<double> hH((size_t)WB * WB), hQ((size_t)n * WB), hmu(n, 0.0);
+  MVBA_HIP(hipMemcpyAsync(hH.data(), H, sizeof(double) * WB * WB, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipMemcpyAsync(hQ.data(), h->dQ, sizeof(double) * (size_t)n * WB, hipMemcpyDeviceToHost, st));
+  if (center) MVBA_HIP(hipMemcpyAsync(hmu.data(), h->dmu, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  MVBA_HIP(hipStreamSynchronize(st));
+  int order[WB];
+  std::iota(order, order + WB, 0);
+  std::sort(order, order + WB, [&](int a, int b) { return hH[(size_t)a * WB + a] > hH[(size_t)b * WB + b]; });
+  for (int i = 0; i < n; ++i) sigma[i] = i < WB ? (T)std::sqrt(std::max(0.0, hH[(size_t)order[i] * WB + order[i]])) : (T)NAN;
+  int hcol[WB] = {};
+  double hsgn[WB] = {};
+  for (int i = 0; i < n_rank; ++i) {
+    const int col = order[i];
+    int big = 0;
+    for (int c = 1; c < n; ++c)
+      if (std::fabs(hQ[(size_t)c * WB + col]) > std::fabs(hQ[(size_t)big * WB + col])) big = c;
+    const double sg = hQ[(size_t)big * WB + col] < 0.0 ? -1.0 : 1.0;  // largest component positive
+    for (int c = 0; c < n; ++c) M[(size_t)c * n_rank + i] = (T)(sg * hQ[(size_t)c * WB + col]);
+    hcol[i] = col;
+    hsgn[i] = sg;
+  }
+  if (means)
+    for (int c = 0; c < n; ++c) means[c] = (T)hmu[c];
+  if (n_rank > h->rank_cap) {
+    if (h->dS) MVBA_HIP(hipFree(h->dS));
+    h->dS = nullptr;
+    MVBA_HIP(hipMalloc(&h->dS, sizeof(T) * (size_t)h->max_rows * n_rank));
+    h->rank_cap = n_rank;
+  }
+  hipEventRecord(h->ev[4], st);
+  std::vector<double> Mg((size_t)n * 4, 0.0);  // the depth loops read the leading basis vectors as [n][4] from dMr, like after run()
+  for (int c = 0; c < n; ++c)
+    for (int i = 0; i < std::min(4, n_rank); ++i) Mg[(size_t)c * 4 + i] = hsgn[i] * hQ[(size_t)c * WB + hcol[i]];
+  MVBA_HIP(hipMemcpyAsync(h->dMr, Mg.data(), sizeof(double) * (size_t)n * 4, hipMemcpyHostToDevice, st));
+  MVBA_HIP(hipMemcpyAsync(dcol, hcol, sizeof(int) * WB, hipMemcpyHostToDevice, st));
+  MVBA_HIP(hipMemcpyAsync(dsgn, hsgn, sizeof(double) * WB, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_take_cols<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, h->dB2, N, n_rank, dcol, dsgn, (T *)h->dS);
+  hipEventRecord(h->ev[5], st);
+  if (S) MVBA_HIP(hipMemcpyAsync(S, h->dS, sizeof(T) * (size_t)N * n_rank, hipMemcpyDeviceToHost, st));  // (null: S stays on the device)
+  MVBA_HIP(hipStreamSynchronize(st));  // (hcol / hsgn are read by the copies above)
+  MVBA_HIP(hipGetLastError());
+  if (timings) {
+    float ms;
+    timings[0] = h->h2d_ms;
+    hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); timings[1] = ms;  // means
+    hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); timings[2] = ms;  // the iteration (in the eigen-solver's slot)
+    hipEventElapsedTime(&ms, h->ev[4], h->ev[5]); timings[3] = ms;  // S out of B
+    timings[4] = it;                                                // iterations (in the sweeps' slot)
+    hipEventElapsedTime(&ms, h->ev[3], h->ev[4]); timings[5] = ms;  // final pass
+  }
+  return MVBA_OK;
+}
+
 constexpr int GS_BLOCKS = 512;
 
 // dW <- the resident base re-weighted by the depths in dz and normalised (see mvsvd_run_scaled)
@@ -2075,16 +2485,24 @@ extern "C" {
 
 int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device, mvsvd_handle **out) {
   if (!out) return fail(MVBA_ERR_BADARG, "null argument");
-  if (max_rows < 1 || n_cols < 1 || n_cols > 2048)
-    return fail(MVBA_ERR_BADARG, "need max_rows >= 1 and 1 <= n_cols <= 2048 (the n_cols x n_cols eigenproblem runs in one workgroup)");
+  if (max_rows < 1 || n_cols < 1 || n_cols > MVSVD_MAX_COLS)
+    return fail(MVBA_ERR_BADARG, "need max_rows >= 1 and 1 <= n_cols <= " + std::to_string(MVSVD_MAX_COLS) + " (three rows of W per image at the engine's camera limit)");
   if (dtype != 0 && dtype != 1) return fail(MVBA_ERR_BADARG, "dtype must be 0 (float32) or 1 (float64)");
   if (device >= 0) MVBA_HIP(hipSetDevice(device));
   mvsvd_handle *h = new mvsvd_handle();
   MVBA_HIP(hipGetDevice(&h->device));
   h->dtype = dtype; h->n = n_cols; h->max_rows = max_rows;
-  const size_t el = dtype ? 8 : 4, nn = (size_t)n_cols * n_cols;
-  const int n_tiles = (n_cols + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
-  h->chunks = chunks_for(max_rows, n_cols);
+  const bool wide = n_cols > WIDE_MIN, dense = n_cols <= JACOBI_MAX;  // beyond JACOBI_MAX no n x n matrix at all: see run_wide
+  const size_t el = dtype ? 8 : 4, nn = dense ? (size_t)n_cols * n_cols : (size_t)WB * WB;
+  const int gram_n = dense ? n_cols : WB;  // the Gram kernels run on the workspace's matrix and on the wide path's 32-column blocks
+  const int n_tiles = (gram_n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
+  h->chunks = chunks_for(max_rows, gram_n);
+  // partial tiles of the Gram kernels: the workspace's own matrix and / or the wide path's blocks (N x 32 and n x 32: three tile pairs)
+  size_t part_tiles = (size_t)h->chunks * n_pairs, part2_tiles = (size_t)GRAM_SLICES * n_pairs;
+  if (wide) {
+    part_tiles = std::max(part_tiles, (size_t)3 * std::max(chunks_for(max_rows, WB), chunks_for(n_cols, WB)));
+    part2_tiles = std::max(part2_tiles, (size_t)3 * GRAM_SLICES);
+  }
 #define SVD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvsvd_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
   SVD_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   for (auto &e : h->ev) SVD_TRY(hipEventCreate(&e));
@@ -2096,8 +2514,23 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   SVD_TRY(hipMalloc((void **)&h->dsum, sizeof(double) * n_cols * COLSUM_SLICES));
   SVD_TRY(hipMalloc((void **)&h->dmu, sizeof(double) * n_cols));
   SVD_TRY(hipMalloc((void **)&h->dsw, sizeof(int)));
-  SVD_TRY(hipMalloc((void **)&h->dpart, sizeof(double) * (size_t)h->chunks * n_pairs * 256));
-  SVD_TRY(hipMalloc((void **)&h->dpart2, sizeof(double) * (size_t)GRAM_SLICES * n_pairs * 256));
+  SVD_TRY(hipMalloc((void **)&h->dpart, sizeof(double) * part_tiles * 256));
+  SVD_TRY(hipMalloc((void **)&h->dpart2, sizeof(double) * part2_tiles * 256));
+  if (wide) {
+    const size_t nb = (size_t)n_cols * WB;
+    // row chunks of Z = W^T B: enough workgroups for the chip beside the n / 64 column blocks, a multiple of 64 rows each
+    const long long col_blocks = (n_cols + WT - 1) / WT, want = std::max<long long>(1, 2048 / col_blocks);
+    h->zrows_per_chunk = std::max<long long>(WT, ((max_rows + want - 1) / want + WT - 1) / WT * WT);
+    h->zchunks = (int)((max_rows + h->zrows_per_chunk - 1) / h->zrows_per_chunk);
+    SVD_TRY(hipMalloc((void **)&h->dQ, sizeof(double) * nb));
+    SVD_TRY(hipMalloc((void **)&h->dZ, sizeof(double) * nb));
+    SVD_TRY(hipMalloc((void **)&h->dQ2, sizeof(double) * nb));
+    SVD_TRY(hipMalloc((void **)&h->dBw, sizeof(double) * (size_t)max_rows * WB));
+    SVD_TRY(hipMalloc((void **)&h->dB2, sizeof(double) * (size_t)max_rows * WB));
+    SVD_TRY(hipMalloc((void **)&h->dzpart, sizeof(double) * (size_t)h->zchunks * nb));
+    SVD_TRY(hipMalloc((void **)&h->dsmall, sizeof(double) * ((size_t)5 * WB * WB + 2 * WB + (size_t)WB * ((n_cols + 255) / 256))));
+    SVD_TRY(hipMalloc((void **)&h->dwflag, sizeof(int) * 2 * WB));
+  }
   SVD_TRY(hipFuncSetAttribute((const void *)k_jacobi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   SVD_TRY(hipFuncSetAttribute((const void *)k_project<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   SVD_TRY(hipFuncSetAttribute((const void *)k_rotate_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -2119,7 +2552,8 @@ void mvsvd_destroy(mvsvd_handle *h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
   for (void *p : {h->dW, h->dS, (void *)h->dG, (void *)h->dV, (void *)h->dV1, (void *)h->dsum, (void *)h->dMr, (void *)h->dmu,
-                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs, (void *)h->ddep, (void *)h->ddflag})
+                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs, (void *)h->ddep, (void *)h->ddflag,
+                  (void *)h->dQ, (void *)h->dZ, (void *)h->dQ2, (void *)h->dBw, (void *)h->dB2, (void *)h->dzpart, (void *)h->dsmall, (void *)h->dwflag})
     if (p) hipFree(p);
   for (auto &e : h->ev)
     if (e) hipEventDestroy(e);

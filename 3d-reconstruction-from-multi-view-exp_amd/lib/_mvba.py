@@ -435,7 +435,7 @@ def svd_factorize(Wt, n_rank, center=False, device=-1):
     if Wt.dtype not in (np.float32, np.float64):
         Wt = Wt.astype(np.float64)
     n_rows, n_cols = Wt.shape
-    if os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 2048:
+    if os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 12288:
         global _svd_cache_atexit
         key = (Wt.dtype.str, n_cols, int(device))
         with _svd_cache_lock:  # (held through the call: a workspace is one matrix and one stream)

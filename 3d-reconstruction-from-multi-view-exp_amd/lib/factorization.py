@@ -7,11 +7,13 @@ reason it cannot reach 5M points.  Here ``W.T`` (the N x n array the callers
 actually hold: perspective_camera_calibration.py:533 passes a transposed view)
 is streamed through ``mvsvd_factorize`` (csrc/mvsvd.hip): thin, never forms Vt.
 
-``n_rank`` is any 1 .. min(W.shape) like the reference's (the projection runs in groups of four
-basis vectors); the one limit is ``W.shape[0] <= 2048`` rows (3m or 2m: the small eigenproblem is
-solved by one workgroup) -- beyond it ``ValueError``.  float64 input gets a second, preconditioned
-pass so that small singular values are as accurate as LAPACK's (the default ``n_rank = 4`` path of
-``perspective_self_calibration`` uses the 4th triplet); output dtype follows the input (B.10).
+Up to 64 rows of ``W`` (3m or 2m), or up to 256 with ``n_rank > 16``: Gram matrix + Jacobi, ``n_rank`` any
+1 .. min(W.shape) like the reference's; float64 input gets a second, preconditioned pass so that small
+singular values are as accurate as LAPACK's (the default ``n_rank = 4`` path of ``perspective_self_calibration``
+uses the 4th triplet).  From 65 rows on (up to 12288 = three per image at the engine's 4096 cameras,
+``n_rank <= 16``; ``ValueError`` beyond either): block power iteration with Rayleigh-Ritz on ``W W^T`` applied
+implicitly -- two passes over ``W`` per iteration, 3-6 iterations for a measurement matrix, the same accuracy
+(the products are formed from ``W`` itself).  Output dtype follows the input (B.10).
 
 Signs: singular vectors are defined up to sign; LAPACK's choice is not a rule.
 Ours: the largest-magnitude entry of every column of ``M`` is positive.  The

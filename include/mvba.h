@@ -189,17 +189,20 @@ int mvba_host_obs_math(const double *X3, const double *cam15, const double *xy2,
  * center != 0: subtract the column means of Wt first (= the row means of W the
  * affine callers remove, affine_camera_calibration.py:224-240); means [n_cols]
  * receives them (may be NULL).
- * Outputs: M [n_cols][n_rank] (= U[:, :r]), sigma [n_cols] (all singular values,
+ * Outputs: M [n_cols][n_rank] (= U[:, :r]), sigma [n_cols] (singular values,
  * descending), S [n_rank][n_rows] (= diag(sigma[:r]) Vt[:r] = M^T W).  Thin: Vt is
  * never formed.  Sign convention: the largest-magnitude component of every column
  * of M is positive (LAPACK's signs are not a rule one can restate).
- * n_rank: any 1 .. n_cols (the projection runs in groups of 4 basis vectors); n_cols <= 2048 (the
- * n_cols x n_cols eigenproblem is solved by one workgroup).
+ * Two routes.  n_cols <= 64, or n_rank > 16 with n_cols <= 256: Gram matrix + Jacobi, n_rank any 1 .. n_cols, sigma = every
+ * singular value.  Otherwise (65 .. 12288 columns = three rows per image at the engine's 4096 cameras, n_rank <= 16; MVBA_ERR_BADARG
+ * beyond either): block power iteration with Rayleigh-Ritz on W^T W applied implicitly, 32 vectors wide, two passes over W per
+ * iteration, no n_cols x n_cols matrix; sigma[0..31] = the block's Ritz values (the leading n_rank converged), sigma[32..] = NaN;
+ * MVBA_ERR_SINGULAR ("SVD did not converge", LAPACK's own failure) after 2000 iterations.
  * Accuracy: float32 data -> one Gram pass accumulated in fp64 (nothing is lost: eps32 >> eps64 *
  * cond^2); float64 data -> a second, preconditioned pass so that small singular values are good to
  * ~eps64 * sigma_1 like LAPACK's gesdd, not to sqrt(eps64) * sigma_1 (see csrc/mvsvd.hip).
  * timings_ms (may be NULL) [6]: H2D, means + Gram, Jacobi, projection (device ms), sweeps,
- * refinement pass (0 for float32). */
+ * refinement pass (0 for float32).  Block route: H2D, means, the iteration, S out of the last product, iterations, final pass. */
 int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtype, int32_t n_rank,
                     int32_t center, void *M, void *sigma, void *S, void *means, double *timings_ms,
                     int32_t device);

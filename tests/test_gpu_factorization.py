@@ -132,6 +132,95 @@ def test_config5_full_size_5m_rows_fp32():
     print(line)
 
 
+def _lapack_rank_r(Wt, r, center=False):
+    W64 = Wt.astype(np.float64)
+    if center:
+        W64 = W64 - W64.mean(axis=0)
+    U, s, Vt = np.linalg.svd(W64.T, full_matrices=False)
+    return s, (U[:, :r] * s[:r]) @ Vt[:r]
+
+
+@pytest.mark.parametrize("n_rows,n_cols,dtype,center", [(5000, 300, np.float64, False), (5000, 1000, np.float64, False), (4000, 3000, np.float64, True),
+                                                        (5000, 1000, np.float32, False), (3000, 12288, np.float64, False)])
+def test_wide_matrices_vs_lapack(n_rows, n_cols, dtype, center):
+    """Many columns (more than 21 / 32 images in W = 3m x N / 2m x N; ref lib/factorization.py:10 takes any shape): the
+    n x n eigenproblem of the Gram route runs in ONE workgroup (0.4 s at 256 columns, 3.3 s at 512) and its projection did not launch
+    at all from ~900 columns on (round 5: tools/time_svd_wide.py).  Beyond 64 columns the leading triplets come from block power iteration with Rayleigh-Ritz
+    on W^T W applied implicitly (csrc/mvsvd.hip, "wide matrices"): sigma, M @ S and M^T M against LAPACK on the same data, up to
+    the engine's camera limit (12288 = 3 x 4096 columns)."""
+    rng = np.random.default_rng(n_cols)
+    Wt = (rng.standard_normal((n_rows, 4)) @ rng.standard_normal((4, n_cols)) + 1e-3 * rng.standard_normal((n_rows, n_cols)) + (40.0 if center else 0.0)).astype(dtype)
+    M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 4, center=center)
+    s_ref, P_ref = _lapack_rank_r(Wt, 4, center)
+    f32 = dtype == np.float32
+    np.testing.assert_allclose(sig[:4].astype(np.float64), s_ref[:4], rtol=2e-6 if f32 else 1e-12)
+    P = M.astype(np.float64) @ S.astype(np.float64)
+    assert np.abs(P - P_ref).max() < (1e-5 if f32 else 1e-12) * s_ref[0]
+    np.testing.assert_allclose(M.astype(np.float64).T @ M.astype(np.float64), np.eye(4), atol=2e-6 if f32 else 1e-12)
+    assert M.shape == (n_cols, 4) and S.shape == (4, n_rows) and sig.shape == (n_cols,)
+    # the block carries 32 Ritz values: the rest of sigma is not computed
+    assert np.all(np.isfinite(sig[:32])) and np.all(np.isnan(sig[32:]))
+    assert 1 <= tm["sweeps"] <= 12  # iterations of the block method (a measurement matrix converges in a handful)
+    if center:
+        np.testing.assert_allclose(mu, Wt.astype(np.float64).mean(axis=0), rtol=0, atol=1e-11)
+
+
+def test_wide_matrices_hard_spectra():
+    """The block iteration where it has to work for its result: a graded spectrum whose fourth singular value is 1e-7 of the first
+    (the products are formed from W, not from an accumulated Gram matrix, and the basis is kept graded -- Ritz order, triangular
+    orthogonalisation, the ROTATED product B Y fed to W^T --, so sigma_4 keeps ~eps sigma_1 / sigma_4 relative accuracy; with a
+    symmetric orthogonalisation and a rotated Z the first version lost that direction to 2e-3);
+    a slowly decaying spectrum; pure Gaussian noise (no gap: ~100 iterations); exact low rank in integers (columns of the block are
+    exactly zero and are refilled); fewer rows than the block is wide; n_rank up to 16."""
+    rng = np.random.default_rng(7)
+
+    def check(Wt, r, tol_sigma, tol_prod):
+        M, sig, S, _mu, tm = _mvba.svd_factorize(Wt, r)
+        s_ref, P_ref = _lapack_rank_r(Wt, r)
+        np.testing.assert_allclose(sig[:r], s_ref[:r], rtol=tol_sigma, atol=1e-14 * s_ref[0])
+        assert np.abs(M @ S - P_ref).max() < tol_prod * s_ref[0]
+        np.testing.assert_allclose(M.T @ M, np.eye(r), atol=1e-12)
+        return tm
+
+    check(_graded(20_000, 400, [1.0, 0.5, 1e-3, 1e-7], seed=3, noise=1e-13), 4, 1e-8, 1e-13)
+    tm = check(_graded(20_000, 400, [1.0, 0.5, 1e-3, 1e-7], seed=3), 4, 1e-8, 1e-13)  # (LAPACK's own sigma_4 is good to eps sigma_1 / sigma_4 = 2e-9)
+    assert tm["sweeps"] <= 4
+    check(_graded(2000, 300, 0.9 ** np.arange(300), seed=4), 4, 1e-12, 1e-12)
+    tm = check(rng.standard_normal((2000, 300)), 3, 1e-11, 1e-9)
+    assert 20 < tm["sweeps"] < 1000
+    check((rng.integers(-3, 4, (1000, 3)) @ rng.integers(-3, 4, (3, 300))).astype(np.float64), 3, 1e-12, 1e-12)
+    check(rng.standard_normal((10, 300)), 3, 1e-12, 1e-12)
+    check(rng.standard_normal((3000, 16)) @ rng.standard_normal((16, 500)) + 1e-4 * rng.standard_normal((3000, 500)), 16, 1e-12, 1e-12)
+
+
+def test_wide_matrix_limits_and_the_python_surface():
+    """n_rank above half the block width and more than 12288 columns are refused with the reason (ValueError); the reference's
+    surface, factorization_method(W, r) with W = (2m x N) for 200 images, goes through the same path."""
+    from lib.factorization import factorization_method
+
+    rng = np.random.default_rng(11)
+    Wt = rng.standard_normal((500, 3)) @ rng.standard_normal((3, 400)) + 1e-4 * rng.standard_normal((500, 400))
+    with pytest.raises(ValueError, match="n_rank <= 16"):
+        _mvba.svd_factorize(Wt, 17)
+    with pytest.raises(ValueError, match="12288"):
+        _mvba.SvdWorkspace(10, 12289, np.float64)
+    M, S = factorization_method(Wt.T, 3)
+    s_ref, P_ref = _lapack_rank_r(Wt, 3)
+    assert M.shape == (400, 3) and S.shape == (3, 500)
+    assert np.abs(M @ S - P_ref).max() < 1e-12 * s_ref[0]
+    # up to 256 columns more than 16 triplets are still served -- by the Gram + Jacobi route (every singular value, 0.1-0.4 s)
+    W100 = rng.standard_normal((800, 100)) * np.logspace(0, -2, 100)[None, :]
+    M20, sig20, S20, _mu, _tm = _mvba.svd_factorize(W100, 20)
+    s_ref, P_ref = _lapack_rank_r(W100, 20)
+    np.testing.assert_allclose(sig20, s_ref, rtol=1e-10)  # all 100 of them
+    assert np.abs(M20 @ S20 - P_ref).max() < 1e-11 * s_ref[0]
+    # ... and from 65 columns on, up to 16 triplets come from the block iteration (sigma: 32 Ritz values, the rest NaN)
+    M4, sig4, S4, _mu, tm4 = _mvba.svd_factorize(W100, 4)
+    s_ref, P_ref = _lapack_rank_r(W100, 4)
+    np.testing.assert_allclose(sig4[:4], s_ref[:4], rtol=1e-12)
+    assert np.abs(M4 @ S4 - P_ref).max() < 1e-11 * s_ref[0] and np.all(np.isnan(sig4[32:]))
+
+
 def _graded(n_rows, n_cols, sigmas, seed=0, noise=0.0):
     rng = np.random.default_rng(seed)
     U, _ = np.linalg.qr(rng.normal(size=(n_rows, len(sigmas))))
@@ -319,13 +408,15 @@ def test_depth_iteration_on_the_device_equals_the_oracle_per_step(method):
     ws.close()
 
 
-@pytest.mark.parametrize("n_points,m,method", [(1500, 3, 1), (1500, 3, 2), (1500, 2, 1), (1200, 16, 1), (1200, 16, 2), (800, 64, 1), (800, 64, 2)])
+@pytest.mark.parametrize("n_points,m,method", [(1500, 3, 1), (1500, 3, 2), (1500, 2, 1), (1200, 16, 1), (1200, 16, 2), (800, 64, 1), (800, 64, 2),
+                                                 (600, 100, 1), (600, 100, 2), (500, 128, 2)])
 def test_depth_iteration_image_counts_vs_oracle(n_points, m, method):
     """Image counts at the edges of the device depth loop's kernel variants, against oracle/depth_oracle.py per step (1e-9): two and
     three views (the reference's loops only need 3 m >= 4 columns; the device loop refused fewer than four until round 5), 16 images
     in fp64 (the rows no longer fit the LDS tiles: the per-lane variants of k_depth_primary / k_dual_apply, which no test ran before),
     64 images (k_dual_gram stages fewer than 128 rows per pass there -- its launch used to fail from 48 images on -- and walks its
-    14 m = 896 tasks in more than one batch per thread)."""
+    14 m = 896 tasks in more than one batch per thread), 100 and 128 images (300 / 384 columns: the factorisation inside the step is
+    the wide path's block iteration, `test_wide_matrices_vs_lapack`)."""
     from lib.perspective_camera_calibration import _create_data_matrix
     from lib.synthetic import make_scene
     from oracle.depth_oracle import HostDepthLoop
