@@ -415,32 +415,86 @@ constexpr int MVSVD_MAX_COLS = 3 * 4096;  // three rows of W per image at MAX_CA
 constexpr int WB = 32;       // block width (= the small solver's order)
 constexpr int WT = 64;       // tile edge of the two products
 
+// The two products share their staging: a 64 x 64 tile of W (kept in its own dtype; converted and centred as the MFMA operand is
+// read) and a 64 x WB tile of the other factor, fetched with 16-byte loads into REGISTERS while the previous tile is multiplied
+// and put into LDS behind a barrier (the first version loaded element by element, stored doubles and waited for every tile's
+// loads before its products: 0.9 / 1.6 TB/s on fp32 / fp64 input).  VEC: the rows of W are 16-byte aligned (n a multiple of
+// 16 / sizeof(T)); otherwise the same tile comes in element by element.
+template <typename T>
+struct WideTile {
+  static constexpr int VEC = 16 / (int)sizeof(T);          // elements per 16-byte load
+  static constexpr int LD = WT + VEC;                       // padded row of the W tile (keeps 16-byte alignment)
+  static constexpr int NV = WT * WT / VEC / 256;            // 16-byte loads per thread and W tile (4 / 8)
+  typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+  vec_t w[NV];
+  double2 o[WT * WB / 2 / 256];                             // the other factor's tile: 4 loads of two doubles per thread
+  // W tile rows r0 .. r0 + 63 (below r_end), columns c0 .. c0 + 63 (below n)
+  __device__ __forceinline__ void load_w(const T *__restrict__ Wt, long long r0, long long r_end, int c0, int n, bool vec) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = threadIdx.x + 256 * u, r = v / (WT / VEC), c = (v % (WT / VEC)) * VEC;
+      const long long row = r0 + r;
+      if (vec && row < r_end && c0 + c < n) {
+        w[u] = *reinterpret_cast<const vec_t *>(Wt + row * n + c0 + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[u][e] = (row < r_end && c0 + c + e < n) ? Wt[row * n + c0 + c + e] : (T)0;
+      }
+    }
+  }
+  // 64 rows x WB doubles from a row-major [.][WB] matrix, rows k0 .. k0 + 63 (below k_end)
+  __device__ __forceinline__ void load_o(const double *__restrict__ O, long long k0, long long k_end) {
+#pragma unroll
+    for (int u = 0; u < WT * WB / 2 / 256; ++u) {
+      const int v = threadIdx.x + 256 * u, r = v / (WB / 2), c = (v % (WB / 2)) * 2;
+      o[u] = (k0 + r < k_end) ? *reinterpret_cast<const double2 *>(O + (k0 + r) * WB + c) : double2{0.0, 0.0};
+    }
+  }
+  __device__ __forceinline__ void store(T (*sW)[LD], double (*sO)[WB + 2]) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int v = threadIdx.x + 256 * u, r = v / (WT / VEC), c = (v % (WT / VEC)) * VEC;
+      *reinterpret_cast<vec_t *>(&sW[r][c]) = w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < WT * WB / 2 / 256; ++u) {
+      const int v = threadIdx.x + 256 * u, r = v / (WB / 2), c = (v % (WB / 2)) * 2;
+      *reinterpret_cast<double2 *>(&sO[r][c]) = o[u];
+    }
+  }
+};
+
 // B[row][j] = sum_c (Wt[row][c] - mu[c]) Q[c][j], j < WB.  One workgroup per 64 rows, wave w its rows 16 w .. 16 w + 15.
 template <typename T>
 __global__ __launch_bounds__(256) void k_wq(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
                                             const double *__restrict__ Q, double *__restrict__ B) {
-  __shared__ double sW[WT][WT + 1], sQ[WT][WB + 1];
+  typedef WideTile<T> Tile;
+  __shared__ __attribute__((aligned(16))) T sW[WT][Tile::LD];
+  __shared__ __attribute__((aligned(16))) double sQ[WT][WB + 2];
+  __shared__ double smu[WT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const long long r0 = (long long)blockIdx.x * WT;
+  const bool vec = n % Tile::VEC == 0;
   svd_d4 acc[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  Tile t;
+  t.load_w(Wt, r0, n_rows, 0, n, vec);
+  t.load_o(Q, 0, n);
   for (int c0 = 0; c0 < n; c0 += WT) {
-    for (int e = threadIdx.x; e < WT * WT; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const long long row = r0 + r;
-      sW[r][c] = (row < n_rows && c0 + c < n) ? (double)Wt[row * n + c0 + c] - (mu ? mu[c0 + c] : 0.0) : 0.0;
-    }
-    for (int e = threadIdx.x; e < WT * WB; e += 256) {
-      const int k = e >> 5, j = e & 31;
-      sQ[k][j] = (c0 + k < n) ? Q[(size_t)(c0 + k) * WB + j] : 0.0;
-    }
+    __syncthreads();  // the previous tile's products are done
+    t.store(sW, sQ);
+    if (threadIdx.x < WT) smu[threadIdx.x] = (mu && c0 + (int)threadIdx.x < n) ? mu[c0 + threadIdx.x] : 0.0;
     __syncthreads();
+    if (c0 + WT < n) {  // the next tile's loads fly under this tile's products
+      t.load_w(Wt, r0, n_rows, c0 + WT, n, vec);
+      t.load_o(Q, c0 + WT, n);
+    }
 #pragma unroll
     for (int kk = 0; kk < WT / 4; ++kk) {
-      const double a = sW[16 * wave + li][4 * kk + lk];
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[4 * kk + lk][li], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[4 * kk + lk][16 + li], acc[1], 0, 0, 0);
+      const int k = 4 * kk + lk;
+      const double a = (double)sW[16 * wave + li][k] - smu[k];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[k][li], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sQ[k][16 + li], acc[1], 0, 0, 0);
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -457,29 +511,37 @@ __global__ __launch_bounds__(256) void k_wq(const T *__restrict__ Wt, long long 
 template <typename T>
 __global__ __launch_bounds__(256) void k_wtb(const T *__restrict__ Wt, long long n_rows, int n, const double *__restrict__ mu,
                                              const double *__restrict__ B, long long rows_per_chunk, double *__restrict__ zpart) {
-  __shared__ double sW[WT][WT + 1], sB[WT][WB + 1];
+  typedef WideTile<T> Tile;
+  __shared__ __attribute__((aligned(16))) T sW[WT][Tile::LD];
+  __shared__ __attribute__((aligned(16))) double sB[WT][WB + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const int c0 = blockIdx.x * WT;
   const long long rb = (long long)blockIdx.y * rows_per_chunk, re = min(n_rows, rb + rows_per_chunk);
+  const bool vec = n % Tile::VEC == 0;
+  const int ca = min(c0 + 16 * wave + li, n - 1);
+  const double mua = mu ? mu[ca] : 0.0;  // this lane's column of W
   svd_d4 acc[2] = {svd_d4{0, 0, 0, 0}, svd_d4{0, 0, 0, 0}};
+  Tile t;
+  if (rb < re) {
+    t.load_w(Wt, rb, re, c0, n, vec);
+    t.load_o(B, rb, re);
+  }
   for (long long r0 = rb; r0 < re; r0 += WT) {
-    for (int e = threadIdx.x; e < WT * WT; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const long long row = r0 + r;
-      sW[r][c] = (row < re && c0 + c < n) ? (double)Wt[row * n + c0 + c] - (mu ? mu[c0 + c] : 0.0) : 0.0;
-    }
-    for (int e = threadIdx.x; e < WT * WB; e += 256) {
-      const int r = e >> 5, j = e & 31;
-      sB[r][j] = (r0 + r < re) ? B[(r0 + r) * WB + j] : 0.0;
-    }
     __syncthreads();
+    t.store(sW, sB);
+    __syncthreads();
+    if (r0 + WT < re) {
+      t.load_w(Wt, r0 + WT, re, c0, n, vec);
+      t.load_o(B, r0 + WT, re);
+    }
+    const int rows_here = (int)min<long long>(WT, re - r0);  // (a zero row of W is -mu after centring: the rows past the end must not count)
 #pragma unroll
     for (int kk = 0; kk < WT / 4; ++kk) {
-      const double a = sW[4 * kk + lk][16 * wave + li];  // A[i][k] = W[row k][column i]
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[4 * kk + lk][li], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[4 * kk + lk][16 + li], acc[1], 0, 0, 0);
+      const int k = 4 * kk + lk;
+      const double a = k < rows_here ? (double)sW[k][16 * wave + li] - mua : 0.0;  // A[i][k] = W[row k][column i]
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[k][li], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[k][16 + li], acc[1], 0, 0, 0);
     }
-    __syncthreads();
   }
   double *out = zpart + (size_t)blockIdx.y * n * WB;
 #pragma unroll

@@ -194,6 +194,23 @@ def test_euclidean_pipeline_end_to_end_at_a_million_points():
     assert max(host.values()) < 0.25 * res["pipeline_wall_s"], host  # (measured: the largest host stage is ~7 % of the wall)
 
 
+def test_euclidean_pipeline_end_to_end_with_a_hundred_images():
+    """The same pipeline at 20,000 points x 100 images, full visibility: W = 300 x N, so every factorisation inside the projective-depth
+    loop is the wide path of the SVD (block power iteration; the Gram + Jacobi route needed ~0.4 s per 300-column eigenproblem, two
+    per depth iteration), the depth updates run their 100-image variants, and BA solves a 893-unknown reduced system on 2 M
+    observations.  Same properties as at a million points."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import time_pipeline
+
+    res = time_pipeline.run(20_000, 100, max_iter=30, tol=1e-2, noise=1e-3)
+    _timing_line("pipeline 20k x 100 (full visibility): " + ", ".join(f"{k} {v:.3f} s" for k, v in res["stages_s"].items())
+                 + f"; wall {res['pipeline_wall_s']:.3f} s, depth iterations {res['depth_iterations']}, LM iterations {res['lm_iterations']}")
+    assert res["finite"] and res["depth_iterations"] >= 1 and res["lm_iterations"] >= 5
+    assert res["rmse_after_self_calibration"] < 5e-2
+    floor = res["noise_floor_expected"]
+    assert 0.8 * floor < res["rmse_after_bundle_adjustment"] < 1.02 * floor, res
+
+
 def _timing_line(text):
     """Full-size runs leave their timing lines under gpurun_out/ (copied to profiles/ by hand)."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
