@@ -559,7 +559,15 @@ __global__ void k_sum_chunks(const double *__restrict__ part, int chunks, long l
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count) return;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * count + e];
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {  // eight loads in flight, added in order (one load per trip waited a memory latency per chunk: 0.14 ms at 400 chunks)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * count + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; c < chunks; ++c) s += part[(size_t)c * count + e];
   out[e] = s;
 }
 
@@ -1122,30 +1130,41 @@ __global__ void k_group_scale(const double *__restrict__ part, int blocks, int n
   if (lane == 0) cs[g] = 1.0 / t;
 }
 
+// Rows too long for the LDS tiles (more than ~57 fp64 / 117 fp32 columns + depths): the lanes of a wave run ACROSS the column
+// groups of a row -- P = ng rounded up to a power of two lanes per row, 64 / P rows per pass (beyond 64 groups: one row, the lanes
+// striding over its groups) -- so that a pass reads and writes one contiguous range; the row's sum of squares (norm 1) is a
+// fixed tree over its lanes.  (Rounds 3-5 had a lane per row walking the 720 bytes of its own row here: 3.9 ms at 1 M x 90 fp64,
+// more than the factorisation it feeds; this form 0.6.)
 template <typename T>
-__global__ __launch_bounds__(256) void k_scale_rows(const T *__restrict__ X, const T *__restrict__ z, long long n_rows, int n,
-                                                    int group, int norm, const double *__restrict__ cs, T *__restrict__ W) {
-  const int ng = n / group;
-  for (long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x; a < n_rows; a += (long long)gridDim.x * blockDim.x) {
-    const T *xr = X + a * n;
-    const T *zr = z + a * ng;
-    T *wr = W + a * n;
-    double rs = 1.0;
+__global__ __launch_bounds__(256) void k_scale_rows_wide(const T *__restrict__ X, const T *__restrict__ z, long long n_rows, int n,
+                                                         int group, int norm, const double *__restrict__ cs, T *__restrict__ W) {
+  const int ng = n / group, lane = threadIdx.x & 63;
+  int P = 1;
+  while (P < ng && P < 64) P <<= 1;
+  const int R = 64 / P, rr = lane / P, g0 = lane - rr * P;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long a0 = wave * R; a0 < n_rows; a0 += n_waves * R) {
+    const long long a = a0 + rr;
+    const bool row_ok = a < n_rows;
+    double ss = 0.0;
     if (norm == 1) {
-      double ss = 0.0;
-      for (int g = 0; g < ng; ++g) {
-        const double zz = (double)zr[g];
-        for (int c = 0; c < group; ++c) {
-          const double w = (double)xr[g * group + c] * zz;
-          ss += w * w;
+      for (int g = g0; g < ng; g += P) {
+        if (row_ok) {
+          const double zz = (double)z[a * ng + g];
+          for (int c = 0; c < group; ++c) {
+            const double w = (double)X[a * n + g * group + c] * zz;
+            ss += w * w;
+          }
         }
       }
-      rs = 1.0 / sqrt(ss);
+      for (int off = P >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);  // (within the row's P lanes; every lane ends with the row's sum)
     }
-    for (int g = 0; g < ng; ++g) {
-      const double f = (double)zr[g] * (norm == 2 ? cs[g] : rs);
-      for (int c = 0; c < group; ++c) wr[g * group + c] = (T)((double)xr[g * group + c] * f);
-    }
+    const double rs = norm == 1 ? 1.0 / sqrt(ss) : 1.0;
+    if (row_ok)
+      for (int g = g0; g < ng; g += P) {
+        const double f = (double)z[a * ng + g] * (norm == 2 ? cs[g] : rs);
+        for (int c = 0; c < group; ++c) W[a * n + g * group + c] = (T)((double)X[a * n + g * group + c] * f);
+      }
   }
 }
 
@@ -1999,6 +2018,8 @@ struct mvsvd_handle {
   double *dQ = nullptr, *dZ = nullptr, *dQ2 = nullptr, *dBw = nullptr, *dB2 = nullptr, *dzpart = nullptr, *dsmall = nullptr;
   int *dwflag = nullptr;
   int zchunks = 1, wide_iters = 0;
+  bool wide = false;
+  bool wide_warm = false, wide_have_q = false, wide_q_center = false;  // warm start of the block iteration inside a depth loop
   long long zrows_per_chunk = 0;
   double h2d_ms = 0.0;
   bool loaded = false;
@@ -2053,7 +2074,7 @@ int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *m
 
 template <typename T>
 int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means, double *timings) {
-  if (h->n > WIDE_MIN && (n_rank <= WB / 2 || h->n > JACOBI_MAX)) return run_wide<T>(h, n_rank, center, M, sigma, S, means, timings);
+  if (h->wide && (n_rank <= WB / 2 || h->n > JACOBI_MAX)) return run_wide<T>(h, n_rank, center, M, sigma, S, means, timings);
   const int n = h->n;
   const long long n_rows = h->n_rows;
   const size_t nn = (size_t)n * n;
@@ -2194,9 +2215,14 @@ int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *m
     launch_gram_n<double>(h, h->dBw, N, WB, nullptr, chunksB, H);
     launch_jacobi_n(h, H, WB, Y, 1e-15);
   };
-  // start: a fixed pseudo-random block, orthonormalised
-  hipLaunchKernelGGL(k_wide_init, dim3(ngrid), dim3(256), 0, st, h->dZ, n, 0x5eedull);
-  orth(h->dZ, h->dQ2, h->dQ, nullptr, 1);
+  // start: a fixed pseudo-random block, orthonormalised -- or, inside a depth loop (the same base re-weighted by slightly different
+  // depths, 50-200 times: mvsvd_run_scaled / mvsvd_depth_step), the Ritz vectors the previous factorisation ended with: one or two
+  // iterations instead of three or four.  A newly loaded matrix (mvsvd_load / mvsvd_load_base) always starts from the fixed block.
+  if (!(h->wide_warm && h->wide_have_q && h->wide_q_center == (center != 0))) {
+    hipLaunchKernelGGL(k_wide_init, dim3(ngrid), dim3(256), 0, st, h->dZ, n, 0x5eedull);
+    orth(h->dZ, h->dQ2, h->dQ, nullptr, 1);
+  }
+  h->wide_have_q = false;  // (until this call has converged)
   double theta[WB], res[WB];
   const int max_iter = 2000;
   int it = 0;
@@ -2239,6 +2265,8 @@ int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *m
     orth(h->dZ, h->dQ2, h->dQ, H, 2 + (unsigned long long)it);
   }
   h->wide_iters = it;
+  h->wide_have_q = converged;
+  h->wide_q_center = center != 0;
   if (!converged)
     return fail(MVBA_ERR_SINGULAR, "SVD did not converge: block power iteration, residual " + std::to_string(worst) + " of sigma_1^2 after " + std::to_string(it) +
                                        " iterations (singular values " + std::to_string(n_rank) + " .. " + std::to_string(WB) + " of this matrix are too close)");
@@ -2317,7 +2345,7 @@ int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
     if (tile_fits<float>(h->n + ng))
       hipLaunchKernelGGL(k_scale_rows_tiled<float>, dim3(sgrid), dim3(256), sizeof(float) * 4 * 64 * (size_t)((h->n + ng) | 1), h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
     else
-      hipLaunchKernelGGL(k_scale_rows<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
+      hipLaunchKernelGGL(k_scale_rows_wide<float>, dim3(sgrid), dim3(256), 0, h->st, (const float *)h->dX, (const float *)h->dz, h->base_rows, h->n, group, norm, cs, (float *)h->dW);
   } else {
     if (norm == 2) {
       hipLaunchKernelGGL(k_group_sumsq<double>, dim3(gblocks), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, h->dgs);
@@ -2326,11 +2354,12 @@ int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
     if (tile_fits<double>(h->n + ng))
       hipLaunchKernelGGL(k_scale_rows_tiled<double>, dim3(sgrid), dim3(256), sizeof(double) * 4 * 64 * (size_t)((h->n + ng) | 1), h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
     else
-      hipLaunchKernelGGL(k_scale_rows<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
+      hipLaunchKernelGGL(k_scale_rows_wide<double>, dim3(sgrid), dim3(256), 0, h->st, (const double *)h->dX, (const double *)h->dz, h->base_rows, h->n, group, norm, cs, (double *)h->dW);
   }
   MVBA_HIP(hipGetLastError());
   h->n_rows = h->base_rows;  // dW now holds the re-weighted base (a mvsvd_load in between may have changed n_rows)
   h->loaded = true;
+  h->wide_warm = true;  // (the block iteration may start from the previous factorisation's vectors: the same base, other depths)
   return MVBA_OK;
 }
 
@@ -2554,7 +2583,10 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
   mvsvd_handle *h = new mvsvd_handle();
   MVBA_HIP(hipGetDevice(&h->device));
   h->dtype = dtype; h->n = n_cols; h->max_rows = max_rows;
-  const bool wide = n_cols > WIDE_MIN, dense = n_cols <= JACOBI_MAX;  // beyond JACOBI_MAX no n x n matrix at all: see run_wide
+  // (MVSVD_WIDE_MIN: experiments -- the column count above which the block iteration takes over, never below its own width)
+  const int wide_min = getenv("MVSVD_WIDE_MIN") ? std::max(WB, atoi(getenv("MVSVD_WIDE_MIN"))) : WIDE_MIN;
+  const bool wide = n_cols > wide_min, dense = n_cols <= JACOBI_MAX;  // beyond JACOBI_MAX no n x n matrix at all: see run_wide
+  h->wide = wide;
   const size_t el = dtype ? 8 : 4, nn = dense ? (size_t)n_cols * n_cols : (size_t)WB * WB;
   const int gram_n = dense ? n_cols : WB;  // the Gram kernels run on the workspace's matrix and on the wide path's 32-column blocks
   const int n_tiles = (gram_n + GT - 1) / GT, n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -2636,6 +2668,7 @@ int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows) {
   h->h2d_ms = ms;
   h->n_rows = n_rows;
   h->loaded = true;
+  h->wide_warm = h->wide_have_q = false;  // a new matrix: the block iteration starts from its fixed block
   return MVBA_OK;
 }
 
@@ -2658,6 +2691,7 @@ int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows) {
   MVBA_HIP(hipStreamSynchronize(h->st));
   h->base_rows = n_rows;
   h->base_loaded = true;
+  h->wide_warm = h->wide_have_q = false;
   h->loaded = false;  // dW holds nothing derived from this base yet
   return MVBA_OK;
 }

@@ -268,6 +268,27 @@ def svd_config5(rows, cols=24):
             "sigma": [float(x) for x in sig[:4]], "sigma_cpu": [float(x) for x in sig_cpu[:4]]}
 
 
+def svd_wide(rows=200_000, cols=300):
+    """A WIDE measurement matrix (100 images x 3 rows of W; the block iteration of csrc/mvsvd.hip, from 65 columns on): rows x cols
+    fp64, rank 4, device time of the iteration + final pass from hipEvents, against LAPACK on the same matrix."""
+    from lib import _mvba
+
+    rng = np.random.default_rng(1)
+    Wt = rng.standard_normal((rows, 4)) @ rng.standard_normal((4, cols)) + 1e-3 * rng.standard_normal((rows, cols))
+    _mvba.svd_factorize(Wt[:20000], 4)  # warm-up
+    M, sig, S, mu, tm = _mvba.svd_factorize(Wt, 4)
+    dev_ms = tm["jacobi_ms"] + tm["refine_ms"]
+    its = int(tm["sweeps"])
+    passes = 2 * its + 1  # B = W Q and Z = W^T B per iteration, B once more at the end
+    t0 = time.perf_counter()
+    s_ref = np.linalg.svd(Wt, compute_uv=False)
+    cpu_s = time.perf_counter() - t0
+    return {"workload": f"{rows} x {cols} fp64, rank 4 (block power iteration, 32 vectors)", "device_ms": dev_ms, "h2d_ms": tm["h2d_ms"],
+            "iterations": its, "passes_over_W": passes, "streamed_bytes": passes * Wt.nbytes,
+            "achieved_GBs": passes * Wt.nbytes / (dev_ms * 1e-3) / 1e9, "frac_of_hbm_peak": passes * Wt.nbytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "sigma_rel_err_vs_lapack": float(np.max(np.abs(sig[:4] - s_ref[:4]) / s_ref[:4])), "cpu_numpy_singular_values_s": cpu_s}
+
+
 def depth_iteration(rows, m=8):
     """The projective-depth iteration (ref lib/perspective_camera_calibration.py:79-129 primary, :166-224
     dual) entirely on the device: `rows` points seen by m images, fp64, one `mvsvd_depth_step` per iteration -- re-weighting,
@@ -731,6 +752,8 @@ def main():
                 out["factorization_svd_config5"] = svd_config5(args.svd_rows)
             if args.depth_rows > 0:
                 out["depth_iteration"] = depth_iteration(args.depth_rows)
+            if args.svd_rows > 0:
+                out["factorization_svd_wide"] = svd_wide()
         if world == 1 and not args.no_config4_shard_leg and not (shard4 or config4 or args.points or args.cams or args.vis):
             eng.close()  # (idempotent) the config-3 engine's ~4 GB go back before the shard's ~11 GB are taken
             try:

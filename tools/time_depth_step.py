@@ -1,4 +1,4 @@
-"""One projective-depth iteration at 5M points x 8 images, fp64, entirely on the device (mvsvd_depth_step): wall time per
+"""One projective-depth iteration at 5M points x 8 images (or: <points> <images>), fp64, entirely on the device (mvsvd_depth_step): wall time per
 iteration and its device phases, both schemes -> a line for profiles/.  (The NumPy form of the same iteration took
 ~6 s at 1 M points on 8 cores: einsum 2.0 + batched 4 x 4 eigh 3.2 + reprojection 0.9.)"""
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "3d-reconstruction-from-multi-view-exp_amd"), ROOT]
 from lib import _mvba  # noqa: E402
 
-n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000, 8
+n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rng = np.random.default_rng(0)
 # a projective scene: points in front of m cameras, homogeneous image coordinates
 X = rng.uniform(-1, 1, (n, 3))
