@@ -317,17 +317,23 @@ def test_bad_arguments():
         _mvba.svd_factorize(np.zeros((10, 4)), 5)
 
 
-@pytest.mark.parametrize("dtype,norm", [(np.float64, 1), (np.float64, 2), (np.float32, 1), (np.float64, 0)])
-def test_depth_weighted_factorisation_from_a_resident_base(dtype, norm):
+@pytest.mark.parametrize("dtype,norm,m", [(np.float64, 1, 8), (np.float64, 2, 8), (np.float32, 1, 8), (np.float64, 0, 8),
+                                          (np.float64, 1, 30), (np.float32, 2, 30), (np.float32, 1, 70), (np.float64, 0, 70)])
+def test_depth_weighted_factorisation_from_a_resident_base(dtype, norm, m):
     """mvsvd_load_base + mvsvd_run_scaled (the projective-depth loops, ref perspective_camera_calibration.py
     :81-87 and :170-179: W = x o z, rows to unit length / image blocks by their squared norm, SVD, 50-200 times):
     the base matrix is uploaded once, every call uploads the depths only and forms W on the device.  Equal to
     loading the host-formed W: the same kernels run on the same numbers (the scaling itself rounds once in the
-    matrix dtype on both sides, in a different order of operations: a few ulp)."""
+    matrix dtype on both sides, in a different order of operations: a few ulp).  30 and 70 images: rows too long for the LDS
+    tiles (k_scale_rows_wide: 32 / 64 lanes per row, and more groups than lanes) and the block iteration behind them, which starts
+    the SECOND call on the same base from the vectors the first one ended with."""
     rng = np.random.default_rng(11)
-    n, m = 40_000, 8
-    x = np.concatenate([rng.normal(size=(n, m, 2)), np.ones((n, m, 1))], axis=2)
+    n = 40_000 if m == 8 else 6_000
     z = 1.0 + 0.2 * rng.uniform(size=(n, m))
+    if m == 8:
+        x = np.concatenate([rng.normal(size=(n, m, 2)), np.ones((n, m, 1))], axis=2)
+    else:  # x o z of rank 4 (like a measurement matrix under its true depths): the leading vectors are well separated from the rest
+        x = (rng.normal(size=(n, 4)) @ rng.normal(size=(4, 3 * m))).reshape(n, m, 3) / z[..., None] + 1e-4 * rng.normal(size=(n, m, 3))
     W = x * z[..., None]
     if norm == 1:
         W = W / np.linalg.norm(W, axis=(1, 2))[:, None, None]
@@ -343,6 +349,21 @@ def test_depth_weighted_factorisation_from_a_resident_base(dtype, norm):
     sg = np.sign(np.sum(M0.astype(np.float64) * M1.astype(np.float64), axis=0))
     np.testing.assert_allclose(M1 * sg, M0, rtol=0, atol=10 * tol)
     np.testing.assert_allclose(S1 * sg[:, None], S0, rtol=0, atol=10 * tol * np.abs(S0).max())
+    if m > 8:  # the warm start: other depths on the same base, against the host-formed matrix loaded afresh
+        z2 = z * (1.0 + 0.01 * rng.uniform(size=z.shape))
+        W2 = x * z2[..., None]
+        if norm == 1:
+            W2 = W2 / np.linalg.norm(W2, axis=(1, 2))[:, None, None]
+        elif norm == 2:
+            W2 = W2 / (W2**2).sum(axis=(0, 2))[None, :, None]
+        M2, s2, S2, tm2 = ws.run_scaled(z2.astype(dtype), 3, norm, 4)
+        assert tm2["sweeps"] <= tm["sweeps"]
+        ws2 = _mvba.SvdWorkspace(n, 3 * m, dtype)
+        M3, s3, S3, _mu, _ = ws2.load(np.ascontiguousarray(W2.reshape(n, 3 * m)).astype(dtype)).run(4)
+        np.testing.assert_allclose(s2[:4].astype(np.float64), s3[:4].astype(np.float64), rtol=tol)
+        sg = np.sign(np.sum(M3.astype(np.float64) * M2.astype(np.float64), axis=0))
+        np.testing.assert_allclose(M2 * sg, M3, rtol=0, atol=10 * tol)
+        ws2.close()
     # and against LAPACK on the host-formed matrix
     s_ref = np.linalg.svd(Wt.astype(np.float64), compute_uv=False)
     np.testing.assert_allclose(s1[:4].astype(np.float64), s_ref[:4], rtol=1e-5 if dtype == np.float32 else 1e-9)
