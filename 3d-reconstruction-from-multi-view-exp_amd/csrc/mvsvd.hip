@@ -1092,6 +1092,20 @@ __global__ __launch_bounds__(256) void k_group_sumsq(const T *__restrict__ X, co
   const int ng = n / group;
   // thread t of the block owns group t % ng of the rows t / ng, t / ng + rows_per_pass, ...: every group's partial is
   // accumulated by a fixed set of threads in a fixed order, then summed over those threads in thread order
+  if (ng > (int)blockDim.x) {  // more groups than threads: a thread owns the groups t, t + 256, ... of the block's rows (blockIdx.x, + gridDim.x, ...)
+    for (int g = threadIdx.x; g < ng; g += blockDim.x) {
+      double acc = 0.0;
+      for (long long a = blockIdx.x; a < n_rows; a += gridDim.x) {
+        const double zz = (double)z[a * ng + g];
+        for (int c = 0; c < group; ++c) {
+          const double w = (double)X[a * n + g * group + c] * zz;
+          acc += w * w;
+        }
+      }
+      part[(size_t)blockIdx.x * ng + g] = acc;
+    }
+    return;
+  }
   const int rows_per_pass = blockDim.x / ng;
   const int g = threadIdx.x % ng, rloc = threadIdx.x / ng;
   double acc = 0.0;
@@ -1379,6 +1393,139 @@ __global__ __launch_bounds__(256) void k_depth_primary(const T *__restrict__ X, 
       tile_store(z, base, rows_here, m, tile + n, ldt, lane);
       wave_sync();
     }
+  }
+  block_sum_to(esum, Epart);
+}
+
+// Rows too long for the LDS tiles (fp64 from ~15 images on): the lanes of a wave run ACROSS the images of a point -- P = m rounded
+// up to a power of two (at most 64) lanes per point, 64 / P points per pass -- so that a pass reads one contiguous range of X
+// and writes one of z; the sums over a point's images (the 4 x 4 companion, the norm and the sign of the new depths) are fixed
+// trees over its lanes, and every lane of a point finds the companion's eigenvector itself.  (The lane-per-point form walks
+// 24 m bytes of its own row per lane: 1.6 ms at 1 M points x 30 images against 0.4 for this one.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_depth_primary_wide(const T *__restrict__ X, const double *__restrict__ Mr, const T *__restrict__ S,
+                                                            long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
+  extern __shared__ double sU[];  // [m][3][4], then per wave [64 points][10 companion sums | 4 eigenvector components]
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) sU[q] = Mr[q];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = 3 * m;
+  double *sg = sU + 12 * (size_t)m + (size_t)wv * 64 * 14;
+  int P = 1;
+  while (P < m && P < 64) P <<= 1;
+  const int R = 64 / P, rr = lane / P, g0 = lane - rr * P;
+  const long long wave = (long long)blockIdx.x * 4 + wv, n_waves = (long long)gridDim.x * 4;
+  double esum = 0.0;
+  // a batch = 64 points: (1) their companions, R points per pass, the lanes across the images; (2) the 64 eigenvectors, a lane per
+  // point (the 4 x 4 Jacobi is ~1000 instructions: run once per pass of R points it was most of the kernel); (3) the new depths
+  for (long long b0 = wave * 64; b0 < n_rows; b0 += n_waves * 64) {
+    for (int sub = 0; sub < 64; sub += R) {
+      const long long a = min(b0 + sub + rr, n_rows - 1);  // (a clamped row repeats the last one: computed, never stored)
+      const bool row_ok = b0 + sub + rr < n_rows;
+      const T *xr = X + a * n;
+      double s[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+      double g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = g0; k < m; k += P) {
+        const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double *u = sU + 12 * k;
+        double c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = (x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = i; j < 4; ++j, ++e) g[e] = fma(c[i], c[j], g[e]);
+        if (row_ok) esum += reproj_err2(u, s, x0, x1, x2);
+      }
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {
+        for (int off = P >> 1; off > 0; off >>= 1) g[e] += __shfl_xor(g[e], off, 64);
+        if (g0 == 0) sg[(sub + rr) * 14 + e] = g[e];
+      }
+    }
+    wave_sync();
+    {
+      double g[10], v[4];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) g[e] = sg[lane * 14 + e];
+      dominant_eigvec4(g, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sg[lane * 14 + 10 + i] = v[i];
+    }
+    wave_sync();
+    for (int sub = 0; sub < 64; sub += R) {
+      const long long a = min(b0 + sub + rr, n_rows - 1);
+      const bool row_ok = b0 + sub + rr < n_rows;
+      const T *xr = X + a * n;
+      double v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = sg[(sub + rr) * 14 + 10 + i];
+      double nrm2 = 0.0, sum = 0.0;
+      for (int k = g0; k < m; k += P) {  // xi_k = C[k] . v (unnormalised)
+        const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+        const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        const double *u = sU + 12 * k;
+        double xi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi = fma((x0 * u[i] + x1 * u[4 + i] + x2 * u[8 + i]) * inv, v[i], xi);
+        nrm2 = fma(xi, xi, nrm2);
+        sum += xi;
+        if (row_ok) z[a * m + k] = (T)(xi * inv);
+      }
+      for (int off = P >> 1; off > 0; off >>= 1) { nrm2 += __shfl_xor(nrm2, off, 64); sum += __shfl_xor(sum, off, 64); }
+      const double sc = (sum < 0.0 ? -1.0 : 1.0) * fast_rsqrt(nrm2);  // unit length, non-negative sum (ref :118, :121)
+      if (row_ok)
+        for (int k = g0; k < m; k += P) z[a * m + k] = (T)((double)z[a * m + k] * sc);  // (this lane's own stores)
+    }
+    wave_sync();
+  }
+  block_sum_to(esum, Epart);
+}
+
+// the dual update's last pass in the same geometry: xi[a][k] = Z_k[a] . w_k, the point's sign rule, z = xi / |x|, reprojection error
+template <typename T>
+__global__ __launch_bounds__(256) void k_dual_apply_wide(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
+                                                         double is3, const double *__restrict__ Mr, const double *__restrict__ w12,
+                                                         long long n_rows, int m, T *__restrict__ z, double *__restrict__ Epart) {
+  extern __shared__ double sm[];  // U4 [m][3][4], w [m][12]
+  double *sU = sm, *sW = sm + 12 * (size_t)m;
+  for (int q = threadIdx.x; q < 12 * m; q += blockDim.x) { sU[q] = Mr[q]; sW[q] = w12[q]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, n = 3 * m;
+  int P = 1;
+  while (P < m && P < 64) P <<= 1;
+  const int R = 64 / P, rr = lane / P, g0 = lane - rr * P;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  double esum = 0.0;
+  for (long long a0 = wave * R; a0 < n_rows; a0 += n_waves * R) {
+    const long long a = min(a0 + rr, n_rows - 1);
+    const bool row_ok = a0 + rr < n_rows;
+    const T *xr = X + a * n;
+    double s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = (double)S[(size_t)i * n_rows + a];
+    const double v4[4] = {s[0] * is0, s[1] * is1, s[2] * is2, s[3] * is3};
+    double sum = 0.0;
+    for (int k = g0; k < m; k += P) {
+      const double x0 = (double)xr[3 * k], x1 = (double)xr[3 * k + 1], x2 = (double)xr[3 * k + 2];
+      const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      const double h0 = x0 * inv, h1 = x1 * inv, h2 = x2 * inv;
+      const double *w = sW + 12 * k;
+      double xi = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xi = fma(v4[i], h0 * w[3 * i] + h1 * w[3 * i + 1] + h2 * w[3 * i + 2], xi);
+      sum += xi;
+      if (row_ok) {
+        z[a * m + k] = (T)(xi * inv);
+        esum += reproj_err2(sU + 12 * k, s, x0, x1, x2);
+      }
+    }
+    for (int off = P >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (sum < 0.0 && row_ok)
+      for (int k = g0; k < m; k += P) z[a * m + k] = (T)(-(double)z[a * m + k]);  // ref :217
   }
   block_sum_to(esum, Epart);
 }
@@ -2333,8 +2480,9 @@ constexpr int GS_BLOCKS = 512;
 // dW <- the resident base re-weighted by the depths in dz and normalised (see mvsvd_run_scaled)
 int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
   const int ng = h->n / group;
-  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
-  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
+  const size_t gs_stride = (size_t)std::max(256, h->n);  // (room for the finest grouping: one group per column)
+  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * gs_stride));
+  double *cs = h->dgs + (size_t)GS_BLOCKS * gs_stride;
   const int sgrid = (int)std::max<long long>(1, std::min<long long>(4096, (h->base_rows + 255) / 256));
   const int gblocks = (int)std::max<long long>(1, std::min<long long>(GS_BLOCKS, h->base_rows / 64 + 1));
   if (h->dtype == 0) {
@@ -2364,6 +2512,7 @@ int scale_base_into_w(mvsvd_handle *h, int group, int norm) {
 }
 
 constexpr int DEPTH_BLOCKS = 2048;  // blocks of the per-point passes / of the dual Gram pass
+constexpr int DEPTH_MAX_IMAGES = 768;  // k_dual_apply_wide keeps U4 and w (24 doubles per image) in LDS: 147,456 B of DEPTH_LDS_MAX
 constexpr size_t DEPTH_LDS_MAX = 148 * 1024;  // dynamic LDS the depth kernels may ask for (+ 2 KiB static in block_sum_to)
 // rows k_dual_gram stages per pass: [rows][3 m | 1] normalised observations + [rows][4] right singular vectors in LDS
 inline int dual_gram_rows(int m) { return (int)std::max<size_t>(1, std::min<size_t>(DG_ROWS_MAX, DEPTH_LDS_MAX / (sizeof(double) * (size_t)(((3 * m) | 1) + 4)))); }
@@ -2397,7 +2546,7 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
       hipLaunchKernelGGL((k_depth_primary<T, true>), dim3(pgrid), dim3(256), sizeof(double) * 12 * m + tile_bytes, st, (const T *)h->dX, h->dMr,
                          (const T *)h->dS, rows, m, (T *)h->dz, Epart);
     else
-      hipLaunchKernelGGL((k_depth_primary<T, false>), dim3(pgrid), dim3(256), sizeof(double) * 12 * m, st, (const T *)h->dX, h->dMr,
+      hipLaunchKernelGGL(k_depth_primary_wide<T>, dim3(pgrid), dim3(256), sizeof(double) * (12 * (size_t)m + 4 * 64 * 14), st, (const T *)h->dX, h->dMr,
                          (const T *)h->dS, rows, m, (T *)h->dz, Epart);
   } else {
     double is[4];
@@ -2416,7 +2565,7 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
       hipLaunchKernelGGL((k_dual_apply<T, true>), dim3(pgrid), dim3(256), sizeof(double) * 24 * m + tile_bytes, st, (const T *)h->dX, (const T *)h->dS,
                          is[0], is[1], is[2], is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
     else
-      hipLaunchKernelGGL((k_dual_apply<T, false>), dim3(pgrid), dim3(256), sizeof(double) * 24 * m, st, (const T *)h->dX, (const T *)h->dS,
+      hipLaunchKernelGGL(k_dual_apply_wide<T>, dim3(pgrid), dim3(256), sizeof(double) * 24 * m, st, (const T *)h->dX, (const T *)h->dS,
                          is[0], is[1], is[2], is[3], h->dMr, w12, rows, m, (T *)h->dz, Epart);
   }
   hipLaunchKernelGGL(k_depth_error, dim3(1), dim3(64), 0, st, Epart, pgrid, (double)rows * (double)m, f0, Eout);
@@ -2482,8 +2631,9 @@ int depth_step_fused(mvsvd_handle *h, int method, double f0, double *E, double *
   hipStream_t st = h->st;
   const double *dX = (const double *)h->dX;
   double *dz = (double *)h->dz;
-  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * 256));
-  double *cs = h->dgs + (size_t)GS_BLOCKS * 256;
+  const size_t gs_stride = (size_t)std::max(256, h->n);  // (room for the finest grouping: one group per column)
+  if (!h->dgs) MVBA_HIP(hipMalloc((void **)&h->dgs, sizeof(double) * (size_t)(GS_BLOCKS + 1) * gs_stride));
+  double *cs = h->dgs + (size_t)GS_BLOCKS * gs_stride;
   const size_t dual_part = (size_t)512 * 4 * m * 256;  // k_dual_gram_mfma: a 16 x 16 tile per wave and image, at most 512 workgroups
   const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + dual_part + (size_t)FZ_MAXM * DEPTH_BLOCKS;
   if (!h->ddep) MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));  // (the fused path is chosen per handle: `need` never changes)
@@ -2634,7 +2784,8 @@ int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device
                         (const void *)k_depth_primary<double, true>, (const void *)k_dual_apply<float, true>, (const void *)k_dual_apply<double, true>,
                         (const void *)k_dual_gram<float>, (const void *)k_dual_gram<double>, (const void *)k_primary_xz, (const void *)k_dual_gram_mfma<2>, (const void *)k_dual_gram_mfma<4>, (const void *)k_dual_gram_mfma<6>, (const void *)k_dual_gram_mfma<8>,
                         (const void *)k_dual_gram_mfma<10>,
-                        (const void *)k_dual_apply_xz})
+                        (const void *)k_dual_apply_xz, (const void *)k_depth_primary_wide<float>, (const void *)k_depth_primary_wide<double>,
+                        (const void *)k_dual_apply_wide<float>, (const void *)k_dual_apply_wide<double>})
     SVD_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEPTH_LDS_MAX));
 #undef SVD_TRY
   *out = h;
@@ -2704,7 +2855,6 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   if (norm < 0 || norm > 2) return fail(MVBA_ERR_BADARG, "norm must be 0 (none), 1 (unit rows) or 2 (column groups by their squared norm)");
   if (n_rank < 1 || n_rank > h->n) return fail(MVBA_ERR_BADARG, "need 1 <= n_rank <= n_cols");
   const int ng = h->n / group;
-  if (ng > 256) return fail(MVBA_ERR_BADARG, "at most 256 column groups");
   MVBA_HIP(hipSetDevice(h->device));
   const size_t el = h->dtype ? 8 : 4;
   if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * h->n));  // (room for any grouping: a later call may ask for a finer one)
@@ -2726,7 +2876,7 @@ int mvsvd_depth_begin(mvsvd_handle *h, int32_t group) {
   if (!h) return fail(MVBA_ERR_BADARG, "null handle");
   if (!h->base_loaded) return fail(MVBA_ERR_STATE, "mvsvd_depth_begin before mvsvd_load_base");
   if (group != 3 || h->n % 3) return fail(MVBA_ERR_BADARG, "the depth iteration works on homogeneous image coordinates: group = 3, n_cols = 3 m");
-  if (h->n / 3 > 256) return fail(MVBA_ERR_BADARG, "at most 256 images");
+  if (h->n / 3 > DEPTH_MAX_IMAGES) return fail(MVBA_ERR_BADARG, "at most " + std::to_string(DEPTH_MAX_IMAGES) + " images in the device depth loop (two 12-double tables per image in a workgroup's LDS)");
   MVBA_HIP(hipSetDevice(h->device));
   const size_t el = h->dtype ? 8 : 4;
   const int ng = h->n / 3;

@@ -430,14 +430,16 @@ def test_depth_iteration_on_the_device_equals_the_oracle_per_step(method):
 
 
 @pytest.mark.parametrize("n_points,m,method", [(1500, 3, 1), (1500, 3, 2), (1500, 2, 1), (1200, 16, 1), (1200, 16, 2), (800, 64, 1), (800, 64, 2),
-                                                 (600, 100, 1), (600, 100, 2), (500, 128, 2)])
+                                                 (600, 100, 1), (600, 100, 2), (500, 128, 2), (1000, 30, 1), (1000, 30, 2), (400, 300, 1), (400, 300, 2),
+                                                 (300, 768, 1)])
 def test_depth_iteration_image_counts_vs_oracle(n_points, m, method):
     """Image counts at the edges of the device depth loop's kernel variants, against oracle/depth_oracle.py per step (1e-9): two and
     three views (the reference's loops only need 3 m >= 4 columns; the device loop refused fewer than four until round 5), 16 images
     in fp64 (the rows no longer fit the LDS tiles: the per-lane variants of k_depth_primary / k_dual_apply, which no test ran before),
     64 images (k_dual_gram stages fewer than 128 rows per pass there -- its launch used to fail from 48 images on -- and walks its
     14 m = 896 tasks in more than one batch per thread), 100 and 128 images (300 / 384 columns: the factorisation inside the step is
-    the wide path's block iteration, `test_wide_matrices_vs_lapack`)."""
+    the wide path's block iteration, `test_wide_matrices_vs_lapack`), 30 / 300 / 768 images (the depth updates with the lanes of a wave
+    ACROSS a point's images -- 32 and 64 lanes per point, more images than lanes -- and the cap of the device loop: 768 images)."""
     from lib.perspective_camera_calibration import _create_data_matrix
     from lib.synthetic import make_scene
     from oracle.depth_oracle import HostDepthLoop
@@ -454,6 +456,34 @@ def test_depth_iteration_image_counts_vs_oracle(n_points, m, method):
         Eo = g.step(method, 1.0)
         assert E == pytest.approx(Eo, rel=1e-9, abs=1e-14)
         np.testing.assert_allclose(ws.depth_read(), g.depths(), rtol=0, atol=1e-9)
+    ws.close()
+
+
+def test_more_than_256_column_groups():
+    """mvsvd_run_scaled with 300 / 900 column groups (the per-group sums of norm 2 were laid out for at most 256 groups per block and
+    the call was refused beyond; the device depth loop ran into the same kernel from 257 images on)."""
+    rng = np.random.default_rng(5)
+    n, cols = 700, 900
+    x = rng.normal(size=(n, 4)) @ rng.normal(size=(4, cols)) + 1e-3 * rng.normal(size=(n, cols))
+    ws = _mvba.SvdWorkspace(n, cols, np.float64)
+    ws.load_base(x)
+    for group in (3, 1):
+        ng = cols // group
+        z = 1.0 + 0.1 * rng.uniform(size=(n, ng))
+        W = (x.reshape(n, ng, group) * z[..., None])
+        W = W / (W**2).sum(axis=(0, 2))[None, :, None]
+        M, s, S, _tm = ws.run_scaled(z, group, 2, 4)
+        s_ref, P_ref = _lapack_rank_r(W.reshape(n, cols), 4)
+        np.testing.assert_allclose(s[:4], s_ref[:4], rtol=1e-11)
+        assert np.abs(M @ S - P_ref).max() < 1e-11 * s_ref[0]
+    ws.close()
+
+
+def test_depth_loop_image_cap():
+    ws = _mvba.SvdWorkspace(50, 3 * 769, np.float64)
+    ws.load_base(np.ones((50, 3 * 769)))
+    with pytest.raises(ValueError, match="768 images"):
+        ws.depth_begin(3)
     ws.close()
 
 
