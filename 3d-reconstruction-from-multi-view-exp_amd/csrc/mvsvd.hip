@@ -1530,73 +1530,87 @@ __global__ __launch_bounds__(256) void k_dual_apply_wide(const T *__restrict__ X
   block_sum_to(esum, Epart);
 }
 
-// dual, pass 1: per block and image the 60 distinct entries of sum_a (v v^T) (x) (x^ x^^T) and the 12 column sums of Z.
-// Task t < 10 m: image t / 10, pair (i <= j) of V4 components t % 10 -> 6 sums over (c <= d);
-// task 10 m <= t < 14 m: image, component i -> 3 column sums.  One thread per task, rows in order, no atomics.
+// dual, pass 1: per block and image the 60 distinct entries of sum_a (v v^T) (x) (x^ x^^T) and the 12 column sums of Z, laid out
+// as 14 "tasks" of 6 values per image for k_dual_reduce: task t < 10 m = image t / 10, pair (i <= j) of V4 components t % 10 -> the 6
+// sums over (c <= d); task 10 m <= t < 14 m = image, component i -> 3 column sums.
+// A thread owns ONE image (all 72 sums of it in registers) and the rows rr = sub, sub + nsplit, ... of the staged batch, with
+// nsplit = 256 / min(m, 256) thread groups per block and a partial per group (summed in group order by k_dual_reduce); more than
+// 256 images go in chunks of 256, the rows staged again per chunk.  Per row a thread reads its image's normalised observation
+// (3 values) and the row's v4 (4, broadcast) for 82 multiply-adds -- rounds 4-5 had a thread per TASK reading five values for
+// seven multiply-adds, and the kernel ran at the LDS read rate: 1.76 ms at 1 M points x 30 images, this form 0.5.
 __constant__ int c_pair_i[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
 __constant__ int c_pair_j[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
 constexpr int DG_ROWS_MAX = 128;  // rows staged per pass of k_dual_gram (fewer when 3 m columns of them do not fit the LDS: dual_gram_rows)
+inline int dual_gram_split(int m) { return std::min(16, 256 / std::min(m, 256)); }  // thread groups (= partials) per block
 template <typename T>
 __global__ __launch_bounds__(256) void k_dual_gram(const T *__restrict__ X, const T *__restrict__ S, double is0, double is1, double is2,
                                                    double is3, long long n_rows, int m, long long rows_per_block, int DG_ROWS,
-                                                   double *__restrict__ part /*[blocks][14 m][6]*/) {
-  // staged per pass: x^ [DG_ROWS][3m] (stride 3m | 1) and v4 [DG_ROWS][4]: the normalisation happens once per (row, image),
-  // not once per task, and the tasks read LDS (rows broadcast within a wave: all its lanes are on the same row)
+                                                   double *__restrict__ part /*[blocks][nsplit][14 m][6]*/) {
+  // staged per pass: x^ [DG_ROWS][3m] (stride 3m | 1) and v4 [DG_ROWS][4]: the normalisation happens once per (row, image)
   extern __shared__ double sg[];
   const int n = 3 * m, ldx = n | 1;
   double *sx = sg, *sv = sg + (size_t)DG_ROWS * ldx;
   const long long a0 = (long long)blockIdx.x * rows_per_block, a1 = min(n_rows, a0 + rows_per_block);
   const double isg[4] = {is0, is1, is2, is3};
-  constexpr int MAXT = 4;  // tasks per thread kept in registers (14 m <= 1024: m <= 73); beyond that the rows are re-staged per batch
-  // few images: 14 m tasks leave most of the 256 threads idle (m = 8: 112) -- the staged rows are then dealt to 2 or 4 groups
-  // of threads (row rr to group rr % nsplit), every group with its own partial (summed in group order by k_dual_reduce)
-  const int tpb = 14 * m <= 64 ? 64 : (14 * m <= 128 ? 128 : 256), nsplit = 256 / tpb, sub = (int)threadIdx.x / tpb, tl = (int)threadIdx.x % tpb;
-  for (int t0 = 0; t0 < 14 * m; t0 += MAXT * 256) {
-    double acc[MAXT][6];
+  const int tpi = min(m, 256), nsplit = min(16, 256 / tpi), sub = (int)threadIdx.x / tpi, kl = (int)threadIdx.x - sub * tpi;
+  for (int k0 = 0; k0 < m; k0 += tpi) {
+    const int k = k0 + kl;
+    const bool mine = sub < nsplit && k < m;
+    double acc[10][6], col[4][3];
 #pragma unroll
-    for (int u = 0; u < MAXT; ++u)
+    for (int p = 0; p < 10; ++p)
 #pragma unroll
-      for (int q = 0; q < 6; ++q) acc[u][q] = 0.0;
+      for (int q = 0; q < 6; ++q) acc[p][q] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[i][c] = 0.0;
     for (long long r0 = a0; r0 < a1; r0 += DG_ROWS) {
       const int nr = (int)min<long long>(DG_ROWS, a1 - r0);
       __syncthreads();
       for (int e = threadIdx.x; e < nr * m; e += 256) {  // (row, image): normalise
-        const int rr = e / m, k = e - rr * m;
-        const T *xr = X + (r0 + rr) * n + 3 * k;
+        const int rr = e / m, kk = e - rr * m;
+        const T *xr = X + (r0 + rr) * n + 3 * kk;
         const double x0 = (double)xr[0], x1 = (double)xr[1], x2 = (double)xr[2];
         const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);
-        double *d = sx + (size_t)rr * ldx + 3 * k;
+        double *d = sx + (size_t)rr * ldx + 3 * kk;
         d[0] = x0 * inv; d[1] = x1 * inv; d[2] = x2 * inv;
       }
       for (int e = threadIdx.x; e < nr * 4; e += 256) sv[e] = (double)S[(size_t)(e & 3) * n_rows + r0 + (e >> 2)] * isg[e & 3];
       __syncthreads();
-#pragma unroll
-      for (int u = 0; u < MAXT; ++u) {
-        const int task = nsplit > 1 ? (u == 0 ? tl : 14 * m) : t0 + u * 256 + (int)threadIdx.x;
-        if (task >= 14 * m) continue;
-        const bool gram = task < 10 * m;
-        const int k = gram ? task / 10 : (task - 10 * m) / 4;
-        const int i = gram ? c_pair_i[task % 10] : (task - 10 * m) % 4, j = gram ? c_pair_j[task % 10] : i;
+      if (mine)
         for (int rr = sub; rr < nr; rr += nsplit) {
-          const double *h = sx + (size_t)rr * ldx + 3 * k;
-          const double h0 = h[0], h1 = h[1], h2 = h[2], vi = sv[4 * rr + i];
-          if (gram) {
-            const double pq = vi * sv[4 * rr + j];
-            acc[u][0] = fma(pq, h0 * h0, acc[u][0]); acc[u][1] = fma(pq, h0 * h1, acc[u][1]); acc[u][2] = fma(pq, h0 * h2, acc[u][2]);
-            acc[u][3] = fma(pq, h1 * h1, acc[u][3]); acc[u][4] = fma(pq, h1 * h2, acc[u][4]); acc[u][5] = fma(pq, h2 * h2, acc[u][5]);
-          } else {
-            acc[u][0] = fma(vi, h0, acc[u][0]); acc[u][1] = fma(vi, h1, acc[u][1]); acc[u][2] = fma(vi, h2, acc[u][2]);
+          const double *hp = sx + (size_t)rr * ldx + 3 * k;
+          const double h[3] = {hp[0], hp[1], hp[2]};
+          const double v[4] = {sv[4 * rr], sv[4 * rr + 1], sv[4 * rr + 2], sv[4 * rr + 3]};
+          const double hh[6] = {h[0] * h[0], h[0] * h[1], h[0] * h[2], h[1] * h[1], h[1] * h[2], h[2] * h[2]};
+          int p = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) col[i][c] = fma(v[i], h[c], col[i][c]);
+#pragma unroll
+            for (int j = i; j < 4; ++j, ++p) {
+              const double pq = v[i] * v[j];
+#pragma unroll
+              for (int q = 0; q < 6; ++q) acc[p][q] = fma(pq, hh[q], acc[p][q]);
+            }
           }
         }
-      }
     }
+    if (mine) {
+      double *o = part + (size_t)(blockIdx.x * nsplit + sub) * 14 * m * 6;
 #pragma unroll
-    for (int u = 0; u < MAXT; ++u) {
-      const int task = nsplit > 1 ? (u == 0 ? tl : 14 * m) : t0 + u * 256 + (int)threadIdx.x;
-      if (task >= 14 * m) continue;
-      double *o = part + ((size_t)(blockIdx.x * nsplit + sub) * 14 * m + task) * 6;
+      for (int p = 0; p < 10; ++p)
 #pragma unroll
-      for (int q = 0; q < 6; ++q) o[q] = acc[u][q];
+        for (int q = 0; q < 6; ++q) o[((size_t)10 * k + p) * 6 + q] = acc[p][q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[((size_t)10 * m + 4 * k + i) * 6 + c] = col[i][c];
+#pragma unroll
+        for (int c = 3; c < 6; ++c) o[((size_t)10 * m + 4 * k + i) * 6 + c] = 0.0;
+      }
     }
   }
 }
@@ -2527,10 +2541,10 @@ int depth_step(mvsvd_handle *h, int method, double f0, double *E, double *timing
   rc = run<T>(h, 4, 0, M.data(), sigma.data(), (T *)nullptr, (T *)nullptr, timings);  // dMr = M, dS = S stay on the device
   if (rc) return rc;
   // ddep: [DEPTH_BLOCKS] error partials | [1] error | G12 [m][144] | V12 [m][144] | colsum [m][12] | w12 [m][12] | dual partials
-  const int dual_blocks = std::max(64, std::min(DEPTH_BLOCKS, 16384 / m));  // (their partials: 14 m x 6 doubles each)
+  const int dsplit = dual_gram_split(m);  // thread groups of k_dual_gram, each with its own partial
+  const int dual_blocks = std::max(64, std::min(DEPTH_BLOCKS, 95000 / m / dsplit));  // (blocks x groups partials of 14 m x 6 doubles: <= ~64 MB)
   const long long rpb = (rows + dual_blocks - 1) / dual_blocks;
   const int gblocks = (int)((rows + rpb - 1) / rpb);
-  const int dsplit = 14 * m <= 64 ? 4 : (14 * m <= 128 ? 2 : 1);  // thread groups of k_dual_gram, each with its own partial
   const size_t need = (size_t)DEPTH_BLOCKS + 8 + (size_t)m * (144 + 144 + 12 + 12) + (size_t)dual_blocks * dsplit * 14 * m * 6;
   if (!h->ddep) MVBA_HIP(hipMalloc((void **)&h->ddep, sizeof(double) * need));  // (m is the handle's: `need` never changes)
   if (!h->ddflag) MVBA_HIP(hipMalloc((void **)&h->ddflag, sizeof(int) * (size_t)(m + 1)));
