@@ -565,13 +565,22 @@ __global__ __launch_bounds__(768, 6) void k_schur_strip(
 //              k-side record of one observation run at the same time on the same L2.
 //   output     partial[unit][104] (81 block, 9 damping, 9 rhs), summed per pair in unit order by
 //              k_schur_reduce into the packed strips: bitwise reproducible, no zero-fill of A.
+#if defined(MVBA_FS)  // (experimental build: the slot form with one lane per item, 64 lists per wave -- csrc/mvba_fs.h; the unit form is not usable in it)
+constexpr int PSTEP = 64;
+#else
 constexpr int PSTEP = 21;                       // items per wave step
+#endif
 constexpr int PROW = 7 * 16;                    // staged bytes per record (slots 0..6, or 1..7)
 constexpr int PWAVE_LDS = PSTEP * (2 * PROW + 5 * 16);  // k rows, l rows, point rows
 constexpr int UNIT_STRIDE = 104;                // doubles per unit partial
 constexpr int SLOT_BUF = PSTEP * (2 * PROW + 3 * 16);  // slot form: one packed staging buffer (k rows, l rows, 48-byte point rows)
+#if defined(MVBA_FS)
+constexpr int SLOT_IDX = 3 * PSTEP;             // k[64] | l[64] | a[64]: one 768-byte DMA row
+constexpr int SLOT_IDX_RING = 2;                // ... staged two steps deep in LDS
+#else
 constexpr int SLOT_IDX = 64;                    // slot form: ints per step in the index (k[21] | l[21] | a[21] | pad): ONE 256-byte DMA row
 constexpr int SLOT_IDX_RING = 3;                // ... staged three steps deep in LDS
+#endif
 #if defined(MVBA_HREC_TIMING)
 #ifndef MVBA_HREC_NBUF
 #define MVBA_HREC_NBUF 3
@@ -584,7 +593,11 @@ constexpr int SLOT_LDS = 3 * SLOT_BUF + SLOT_IDX_RING * SLOT_IDX * 4;  // three 
 // (LDS is handed out in 512-byte granules: 9 x 17,920 = 161,280 of the 163,840 bytes.  16 bytes are all a wave could still have --
 // with 48 more, a CU holds eight waves, the range's 284 are no longer all resident and the launch spends 6 ms in pacing time-outs:
 // profiles/r05_pace_poll.txt)
+#if defined(MVBA_FS)
+static_assert(3 * ((SLOT_LDS + 511) / 512 * 512) <= 160 * 1024, "three waves per CU");
+#else
 static_assert(9 * ((SLOT_LDS + 511) / 512 * 512) <= 160 * 1024, "nine waves per CU");
+#endif
 #endif
 
 __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_wave_uniform) {
@@ -1044,6 +1057,9 @@ __device__ __forceinline__ void schur_pairs_unit(char *wbuf, const int lane, con
 #if defined(MVBA_HREC_TIMING)  // timing-only variant of both kernels (round 5, measured and not built: see the header)
 #include "mvba_hrec_timing.h"
 #endif
+#if defined(MVBA_FS)
+#include "mvba_fs.h"
+#endif
 
 
 // One wave per block: a wave works alone, and in a wider block its LDS and wave slots stay taken until
@@ -1168,6 +1184,9 @@ __device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc,
     schur_slots_hrec<true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, rec_r, res_r, PB, c, 1.0 / f0, partial, su, pace, 0);
   else
     schur_slots_hrec<false>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, rec_r, res_r, PB, c, 1.0 / f0, partial, su, pace, 0);
+#elif defined(MVBA_FS)
+  if (flags & 1) schur_slots_fs<true>(smem_pairs, (int)threadIdx.x, beg, nsteps, it_k, rec_r, PB, c, 1.0 / f0, partial, su, pace);
+  else schur_slots_fs<false>(smem_pairs, (int)threadIdx.x, beg, nsteps, it_k, rec_r, PB, c, 1.0 / f0, partial, su, pace);
 #else
   if (flags & 1)
     schur_pairs_unit<true, false, true>(smem_pairs, (int)threadIdx.x, beg, nsteps * PSTEP, it_k, it_l, it_a, rec_r, PB, c, 1.0 / f0, partial, su, pace);
@@ -1181,7 +1200,11 @@ __device__ __forceinline__ void schur_slots_wave(const int4 *__restrict__ wdesc,
       double *__restrict__ partial, int *__restrict__ head, int nR, int wpr, const int *__restrict__ seg_end,            \
       int *__restrict__ prog, int nseg, int lag, long long *__restrict__ trace, const long long *__restrict__ range_o0
 #ifndef MVBA_SLOT_WAVES_PER_SIMD
+#if defined(MVBA_FS)
+#define MVBA_SLOT_WAVES_PER_SIMD 1
+#else
 #define MVBA_SLOT_WAVES_PER_SIMD 3
+#endif
 #endif
 __global__ __launch_bounds__(64, MVBA_SLOT_WAVES_PER_SIMD) void k_schur_slots(MVBA_SLOTS_ARGS) {
   schur_slots_wave(wdesc, wunits, it_k, it_l, it_a, rec, PB, c, f0, partial, head, nR, wpr, seg_end, prog, nseg, lag, trace, range_o0);
