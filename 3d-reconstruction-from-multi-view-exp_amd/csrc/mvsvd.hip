@@ -2406,7 +2406,11 @@ int run_wide(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *m
     MVBA_HIP(hipMemcpyAsync(hH.data(), H, sizeof(double) * WB * WB, hipMemcpyDeviceToHost, st));
     MVBA_HIP(hipMemcpyAsync(res, dres, sizeof(double) * WB, hipMemcpyDeviceToHost, st));
     MVBA_HIP(hipStreamSynchronize(st));
-    for (int j = 0; j < WB; ++j) theta[j] = hH[(size_t)j * WB + j];
+    for (int j = 0; j < WB; ++j) {
+      theta[j] = hH[(size_t)j * WB + j];
+      if (!std::isfinite(theta[j]) || !std::isfinite(res[j]))  // (before anything is compared: max() and sort() swallow a NaN)
+        return fail(MVBA_ERR_SINGULAR, "SVD did not converge (non-finite values in the measurement matrix)");
+    }
     int order[WB];
     std::iota(order, order + WB, 0);
     std::sort(order, order + WB, [&](int a, int b) { return theta[a] > theta[b]; });

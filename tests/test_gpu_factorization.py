@@ -193,6 +193,18 @@ def test_wide_matrices_hard_spectra():
     check(rng.standard_normal((3000, 16)) @ rng.standard_normal((16, 500)) + 1e-4 * rng.standard_normal((3000, 500)), 16, 1e-12, 1e-12)
 
 
+def test_wide_matrices_degenerate_inputs():
+    """An all-zero matrix (every singular value 0, any orthonormal basis is a valid answer) and a matrix with a NaN in it (LAPACK raises
+    LinAlgError("SVD did not converge"); so does the block iteration, at its first residual)."""
+    M, sig, S, _mu, _tm = _mvba.svd_factorize(np.zeros((500, 300)), 3)
+    assert np.all(sig[:32] == 0.0) and np.all(S == 0.0)
+    np.testing.assert_allclose(M.T @ M, np.eye(3), atol=1e-12)
+    W = np.random.default_rng(2).standard_normal((500, 300))
+    W[17, 123] = np.nan
+    with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
+        _mvba.svd_factorize(W, 3)
+
+
 def test_wide_matrix_limits_and_the_python_surface():
     """n_rank above half the block width and more than 12288 columns are refused with the reason (ValueError); the reference's
     surface, factorization_method(W, r) with W = (2m x N) for 200 images, goes through the same path."""
