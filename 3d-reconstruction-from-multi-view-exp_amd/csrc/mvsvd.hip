@@ -2275,6 +2275,8 @@ int run(mvsvd_handle *h, int n_rank, int center, T *M, T *sigma, T *S, T *means,
   MVBA_HIP(hipMemcpyAsync(hV.data(), h->dV, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
   if (center) MVBA_HIP(hipMemcpyAsync(hmu.data(), h->dmu, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   MVBA_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i)  // (np.linalg.svd raises LinAlgError("SVD did not converge") on such input; max() and sort() below would swallow the NaN)
+    if (!std::isfinite(hG[(size_t)i * n + i])) return fail(MVBA_ERR_SINGULAR, "SVD did not converge (non-finite values in the measurement matrix)");
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::sort(order.begin(), order.end(), [&](int a, int b) { return hG[(size_t)a * n + a] > hG[(size_t)b * n + b]; });

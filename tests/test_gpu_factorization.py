@@ -203,6 +203,8 @@ def test_wide_matrices_degenerate_inputs():
     W[17, 123] = np.nan
     with pytest.raises(np.linalg.LinAlgError, match="did not converge"):
         _mvba.svd_factorize(W, 3)
+    with pytest.raises(np.linalg.LinAlgError, match="did not converge"):  # ... and the Gram + Jacobi route (it returned sigma = 0 until round 5)
+        _mvba.svd_factorize(np.ascontiguousarray(W[:, 100:124]), 3)
 
 
 def test_wide_matrix_limits_and_the_python_surface():
