@@ -1252,6 +1252,208 @@ __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restri
   }
 }
 
+// ------------------------------------------------------------------ K3 (dense visibility: every point seen by every camera)
+// The reference's own scenes (euclidiean_reconstruction.py, affine_reconstruction.py, BASELINE config 2) and the pipeline test at
+// 1 M points x 12 images have FULL visibility and a dozen or two cameras.  The pair-major forms above then walk m (m + 1) / 2 items
+// per point through gathers and an index of their own (78 items and 0.9 GB of index per million points at 12 cameras: 4.9 ms per
+// solve, 63 ps per item against 30 at config 3) although a point's m records are ONE contiguous range and every pair is present.
+// With E_a^-1 = R_a R_a^T (3 x 3 Cholesky) and the scaled camera Jacobian J~_ak (2 x 9: f | u, v (1 / f0) | t (-J_X) | omega)
+//   G_a = [R_a^T J_Xak^T J~_ak]_k   (3 x 9m),        A = blockdiag(2 H_k + c diag(2 H_k)) - 4 sum_a G_a^T G_a,
+//   H_k = sum_a J~_ak^T J~_ak,                        b_k = 2 sum_a J~_ak^T (J_Xak E_a^-1 dP_a - e_ak)
+// -- one symmetric rank-3N update of a 9m x 9m matrix: a GEMM, on the f64 matrix cores, over records streamed ONCE.
+// A workgroup takes DCH points at a time: their records and point rows go into LDS with contiguous 16-byte loads; a thread per
+// observation forms J_X R and the right-hand-side vector w; the rows of G are written to LDS once (each is read by up to T tile
+// pairs); wave w then owns the 16 x 16 tile pairs w, w + 4, ... of the upper triangle (four consecutive rows of G -- of whichever
+// points -- are one v_mfma_f64_16x16x4: no padding of K) and the per-camera tiles [J~ | w]^T [J~ | w] (two points per MFMA) of the
+// cameras w, w + 4, ...  Partial tiles per workgroup, summed in workgroup order by k_schur_dense_finish: no atomics, bitwise
+// reproducible.  No index at all: mvba_create skips the pair-major index for such scenes.
+typedef double mvba_d4 __attribute__((ext_vector_type(4)));
+#ifndef MVBA_DENSE_KO
+#define MVBA_DENSE_KO 0  // (timing-only builds: bit 0 no main MFMAs, 1 no rows of G, 2 no per-observation phase, 3 no per-camera MFMAs)
+#endif
+constexpr int DCH = 8;             // points per chunk
+constexpr int DENSE_MAX_TILES = 12;  // 9 m <= 192: m <= 21 cameras (78 tile pairs: 20 accumulators of 4 doubles per lane)
+__device__ __forceinline__ int dense_tile_elem(int row, int col) { return ((row >> 2) << 6) | ((row & 3) << 4) | col; }  // C/D layout: col = l & 15, row = (l >> 4) + 4 reg
+
+template <int T>
+__global__ __launch_bounds__(256) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N, int m,
+                                                     double cu, double *__restrict__ part) {
+  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T, NCW = ((16 * T) / 9 + 3) / 4;
+  extern __shared__ double2 dsm[];
+  double2 *sRec = dsm;                                        // [DCH m][8]
+  double2 *sAux = sRec + (size_t)DCH * m * REC;               // [DCH m][3]: (J_X R)[:, r] for r = 0..2
+  double *sB = reinterpret_cast<double *>(sAux + (size_t)DCH * m * 3);  // [DCH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
+  double *sPB = sB + (size_t)DCH * m * 32;                    // [DCH][16]
+  double *sG = sPB + DCH * PBS;                               // [3 DCH][W]
+  int *sRow = reinterpret_cast<int *>(sG + (size_t)3 * DCH * W);  // [DCH m]: 3 x the observation's point of the chunk
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  int ti[NPW], tj[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {  // pair p = 4 q + wave of the upper triangle, row-major
+    int p = 4 * q + wave, a = 0;
+    if (p >= P) p = P - 1;         // (a spare slot repeats the last pair: computed, never stored)
+    while (p >= T - a) { p -= T - a; ++a; }
+    ti[q] = a; tj[q] = a + p;
+  }
+  mvba_d4 acc[NPW], cacc[NCW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) acc[q] = mvba_d4{0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < NCW; ++q) cacc[q] = mvba_d4{0, 0, 0, 0};
+  // what no phase below ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
+  for (int e = threadIdx.x; e < 3 * DCH * W; e += 256) sG[e] = 0.0;
+  for (int e = threadIdx.x; e < DCH * m * 32; e += 256) sB[e] = 0.0;
+  const long long n_chunks = (N + DCH - 1) / DCH;
+  // a chunk's records (DCH m x 8 double2, at most 6 per thread) and point rows (DCH x 8 double2) are fetched into registers while
+  // the previous chunk is multiplied, and put into LDS behind a barrier
+  constexpr int NPRE = (DCH * ((16 * T) / 9) * REC + 255) / 256;
+  double2 pre[NPRE], prepb;
+  auto fetch = [&](long long ch) {
+    const long long a0 = ch * DCH;
+    const int np = (int)min<long long>(DCH, N - a0), cnt = np * m * REC;
+    const double2 *src = rec + (size_t)a0 * m * REC;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      pre[u] = e < cnt ? src[e] : double2{0.0, 0.0};
+    }
+    const int ep = threadIdx.x;
+    prepb = ep < np * (PBS / 2) ? reinterpret_cast<const double2 *>(PB + (size_t)a0 * PBS)[ep] : double2{0.0, 0.0};
+  };
+  if (blockIdx.x < n_chunks) fetch(blockIdx.x);
+  const int t9 = threadIdx.x / 9, j9 = threadIdx.x - 9 * t9;  // phase 2: thread -> (observation t9 of a pass of 28, column j9)
+  for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const long long a0 = ch * DCH;
+    const int np = (int)min<long long>(DCH, N - a0);
+    __syncthreads();  // the previous chunk's products are done
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      if (e < DCH * m * REC) sRec[e] = pre[u];
+    }
+    if (threadIdx.x < DCH * (PBS / 2)) reinterpret_cast<double2 *>(sPB)[threadIdx.x] = prepb;
+    __syncthreads();
+    if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
+#if !(MVBA_DENSE_KO & 4)
+    // phase 1, a thread per observation (past the last point of the last chunk: zero records give zero rows): J_X R with
+    // E^-1 = R R^T (R lower triangular), w = J_X E^-1 dP - e, and the two camera rows [J~ | w]
+    for (int o = threadIdx.x; o < DCH * m; o += 256) {
+      const int pa = o / m;
+      const double *pb = sPB + pa * PBS;
+      double r00 = 0.0, r10 = 0.0, r20 = 0.0, r11 = 0.0, r21 = 0.0, r22 = 0.0;
+      if (pa < np) {
+        r00 = sqrt(pb[0]);
+        const double i00 = 1.0 / r00;
+        r10 = pb[1] * i00; r20 = pb[2] * i00;
+        r11 = sqrt(pb[3] - r10 * r10);
+        r21 = (pb[4] - r20 * r10) / r11;
+        r22 = sqrt(pb[5] - r20 * r20 - r21 * r21);
+      }
+      const double2 x0 = sRec[o * REC], x1 = sRec[o * REC + 1], x2 = sRec[o * REC + 2], e = sRec[o * REC + 7];
+      sAux[o * 3 + 0] = double2{x0.x * r00 + x1.x * r10 + x2.x * r20, x0.y * r00 + x1.y * r10 + x2.y * r20};
+      sAux[o * 3 + 1] = double2{x1.x * r11 + x2.x * r21, x1.y * r11 + x2.y * r21};
+      sAux[o * 3 + 2] = double2{x2.x * r22, x2.y * r22};
+      sRow[o] = 3 * pa;
+      const double2 f = sRec[o * REC + 3], w0 = sRec[o * REC + 4], w1 = sRec[o * REC + 5], w2 = sRec[o * REC + 6];
+      const double live = pa < np ? 1.0 : 0.0;
+      double *bx = sB + (size_t)o * 32, *by = bx + 16;
+      bx[0] = f.x; by[0] = f.y;
+      bx[1] = cu * live; by[1] = 0.0;
+      bx[2] = 0.0; by[2] = cu * live;
+      bx[3] = -x0.x; by[3] = -x0.y; bx[4] = -x1.x; by[4] = -x1.y; bx[5] = -x2.x; by[5] = -x2.y;
+      bx[6] = w0.x; by[6] = w0.y; bx[7] = w1.x; by[7] = w1.y; bx[8] = w2.x; by[8] = w2.y;
+      bx[9] = (x0.x * pb[6] + x1.x * pb[7] + x2.x * pb[8] - e.x) * live;
+      by[9] = (x0.y * pb[6] + x1.y * pb[7] + x2.y * pb[8] - e.y) * live;
+    }
+#endif
+    __syncthreads();
+#if !(MVBA_DENSE_KO & 2)
+    // phase 2, a thread per (observation, column of J~): the three rows of G at column 9 k + j
+    if (t9 < 28)
+      for (int o = t9; o < DCH * m; o += 28) {
+        const int row3 = sRow[o], k = o - (row3 / 3) * m;
+        const double jx = sB[(size_t)o * 32 + j9], jy = sB[(size_t)o * 32 + 16 + j9];
+        double *g = sG + (size_t)row3 * W + 9 * k + j9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double2 jr = sAux[o * 3 + r];
+          g[(size_t)r * W] = jr.x * jx + jr.y * jy;
+        }
+      }
+#endif
+    __syncthreads();
+#if !(MVBA_DENSE_KO & 1)
+#pragma unroll
+    for (int g = 0; g < 3 * DCH / 4; ++g) {  // four rows of G per MFMA
+      const double *row = sG + (size_t)(4 * g + lk) * W + li;
+#pragma unroll
+      for (int q = 0; q < NPW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ti[q]], row[16 * tj[q]], acc[q], 0, 0, 0);
+    }
+#endif
+#if !(MVBA_DENSE_KO & 8)
+#pragma unroll
+    for (int g = 0; g < DCH / 2; ++g) {  // the per-camera tiles: rows (point 2 g, x), (2 g, y), (2 g + 1, x), (2 g + 1, y)
+      const int pa = 2 * g + (lk >> 1), d = lk & 1;
+#pragma unroll
+      for (int q = 0; q < NCW; ++q) {
+        const int k = min(4 * q + wave, m - 1);
+        const double v = sB[(size_t)(pa * m + k) * 32 + 16 * d + li];
+        cacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, cacc[q], 0, 0, 0);
+      }
+    }
+#endif
+  }
+  double *out = part + (size_t)blockIdx.x * (P + m) * 256;
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int p = 4 * q + wave;
+    if (p < P)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)p * 256 + r * 64 + lane] = acc[q][r];
+  }
+#pragma unroll
+  for (int q = 0; q < NCW; ++q) {
+    const int k = 4 * q + wave;
+    if (k < m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(P + k) * 256 + r * 64 + lane] = cacc[q][r];
+  }
+}
+
+// One wave per element of the packed strips [A | b]: the workgroups' partial tiles summed in workgroup order (lane l takes the
+// workgroups l, l + 64, ... in order, then a fixed tree).
+__global__ __launch_bounds__(256) void k_schur_dense_finish(int m, int T, int blocks, const double *__restrict__ part, double c,
+                                                            double *__restrict__ Afull, double *__restrict__ bfull) {
+  const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, P = T * (T + 1) / 2;
+  const long long nA = (long long)strip_offset(m, m);
+  if (e >= nA + 9 * m) return;
+  const size_t bstride = (size_t)(P + m) * 256;
+  auto total = [&](int tile, int elem) {
+    double t = 0.0;
+    for (int b = lane; b < blocks; b += 64) t += part[(size_t)b * bstride + (size_t)tile * 256 + elem];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    return t;  // (valid in lane 0)
+  };
+  if (e < nA) {
+    int k = 0;
+    while (k + 1 < m && (long long)strip_offset(k + 1, m) <= e) ++k;
+    const int Wk = 9 * (m - k), rem = (int)(e - (long long)strip_offset(k, m)), i = rem / Wk, cr = rem - i * Wk, l = k + cr / 9, j = cr - 9 * (l - k);
+    const int gi = 9 * k + i, gj = 9 * l + j, lo = min(gi, gj), hi = max(gi, gj), ti = lo >> 4, tj = hi >> 4;
+    double v = -4.0 * total(ti * T - ti * (ti - 1) / 2 + (tj - ti), dense_tile_elem(lo & 15, hi & 15));
+    if (k == l) {
+      const double hk = total(P + k, dense_tile_elem(i, j));
+      v += 2.0 * hk * (i == j ? 1.0 + c : 1.0);  // G_k and its Marquardt term c diag(G_k)   (ref :123-125)
+    }
+    if (lane == 0) Afull[e] = v;
+  } else {
+    const int q = (int)(e - nA), k = q / 9, j = q - 9 * k;
+    const double v = 2.0 * total(P + k, dense_tile_elem(j, 9));  // 2 Jc_k^T (Jx_k E^-1 dP - e)
+    if (lane == 0) bfull[q] = v;
+  }
+}
+
 // ------------------------------------------------------------------ K4: gauge strip + Cholesky
 // The reduced system is SPD (Gauss-Newton Schur complement with Marquardt damping), so
 // the reference's np.linalg.solve (LU, ref :146) is replaced by a blocked Cholesky
@@ -2874,7 +3076,7 @@ __global__ void k_idx_interleave(long long n_steps, const int *__restrict__ st_k
 }  // namespace
 
 // ------------------------------------------------------------------ host side
-enum { SCHUR_STRIP = 0, SCHUR_PAIRS = 1, SCHUR_SLOTS = 2 };
+enum { SCHUR_STRIP = 0, SCHUR_PAIRS = 1, SCHUR_SLOTS = 2, SCHUR_DENSE = 3 };
 struct mvba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -2923,6 +3125,8 @@ struct mvba_handle {
       *d_q_head = nullptr;
   int4 *d_units = nullptr;
   double *d_partial = nullptr;
+  double *d_dense_part = nullptr;     // SCHUR_DENSE: partial tiles per workgroup
+  int dense_blocks = 0, dense_tiles = 0;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
@@ -3327,7 +3531,18 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (v > 0.0 && v < 1.0) h->check_solve_tol = v;
   }
   if (m > 65535) h->schur_mode = SCHUR_STRIP;
-  h->use_pairs = h->schur_mode != SCHUR_STRIP;
+  {  // full visibility with up to 21 cameras (every point's observations are cameras 0 .. m - 1 in order): the dense form, no index
+    bool dense_ok = m >= 1 && 9 * m <= 16 * DENSE_MAX_TILES && nobs == N * (long long)m && N > 0;
+    for (long long a = 0; a < N && dense_ok; ++a) {
+      if (p->pt_ptr[a + 1] - p->pt_ptr[a] != m) { dense_ok = false; break; }
+      const int *ci = p->cam_idx + p->pt_ptr[a];
+      for (int k = 0; k < m; ++k)
+        if (ci[k] != k) { dense_ok = false; break; }
+    }
+    const char *ev = getenv("MVBA_SCHUR");
+    if (dense_ok && (!ev || !strcmp(ev, "dense"))) h->schur_mode = SCHUR_DENSE;
+  }
+  h->use_pairs = h->schur_mode != SCHUR_STRIP && h->schur_mode != SCHUR_DENSE;
   std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units, st_k, st_l, st_a, wunits, seg_end;
   std::vector<int4> units, wdesc;
   if (h->use_pairs) {
@@ -4008,6 +4223,12 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_PL, 0, sizeof(double) * 9 * std::max<long long>(N, 1)));
   if (want_strip) TRYH(hipMemcpy(h->d_chunk_ptr, chunk_ptr.data(), sizeof(long long) * chunk_ptr.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
+  if (h->schur_mode == SCHUR_DENSE) {  // partial tiles of k_schur_dense: (tile pairs + one per camera) x 256 doubles per workgroup
+    const int T = (9 * m + 15) / 16;
+    h->dense_tiles = T * (T + 1) / 2 + m;
+    h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + DCH - 1) / DCH, 1024));
+    TRY(dmalloc(&h->d_dense_part, (size_t)h->dense_blocks * h->dense_tiles * 256));
+  }
   if (h->use_pairs) {
     const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
     if (!h->index_on_device) { TRY(dmalloc(&h->d_it_k, it_k.size())); TRY(dmalloc(&h->d_it_l, it_l.size())); TRY(dmalloc(&h->d_it_a, it_a.size())); }
@@ -4114,7 +4335,7 @@ void mvba_destroy(mvba_handle *h) {
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_tile_slot, h->d_splits, h->d_PLsplit, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
-                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_sim, h->d_bar, h->d_wdesc,
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_dense_part, h->d_sim, h->d_bar, h->d_wdesc,
                   h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0, h->d_it_x, h->d_cam18, h->d_dxi10};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
@@ -4248,6 +4469,33 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     }
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((long long)m * (m + 1) / 2)), dim3(128), 0, h->stream, m, h->d_unit_ptr,
                        h->d_partial, d_A, d_b, h->d_q_head);
+  } else if (h->schur_mode == SCHUR_DENSE) {
+    Timed t(h, MVBA_K_SCHUR);
+    const int T = (9 * m + 15) / 16;
+    const size_t lds = sizeof(double2) * (size_t)DCH * m * (REC + 3) + sizeof(double) * ((size_t)DCH * m * 32 + (size_t)DCH * PBS + (size_t)3 * DCH * 16 * T) +
+                       sizeof(int) * (size_t)DCH * m;
+    auto launch = [&](auto kern) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(256), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
+                         1.0 / h->f0, h->d_dense_part);
+    };
+    switch (T) {
+      case 1: launch(k_schur_dense<1>); break;
+      case 2: launch(k_schur_dense<2>); break;
+      case 3: launch(k_schur_dense<3>); break;
+      case 4: launch(k_schur_dense<4>); break;
+      case 5: launch(k_schur_dense<5>); break;
+      case 6: launch(k_schur_dense<6>); break;
+      case 7: launch(k_schur_dense<7>); break;
+      case 8: launch(k_schur_dense<8>); break;
+      case 9: launch(k_schur_dense<9>); break;
+      case 10: launch(k_schur_dense<10>); break;
+      case 11: launch(k_schur_dense<11>); break;
+      default: launch(k_schur_dense<12>); break;
+    }
+    const long long n_el = (long long)nA + 9 * m;
+    hipLaunchKernelGGL(k_schur_dense_finish, dim3((unsigned)((n_el + 3) / 4)), dim3(256), 0, h->stream, m, T, h->dense_blocks,
+                       (const double *)h->d_dense_part, c, d_A, d_b);
   } else if (h->nobs) {
     Timed t(h, MVBA_K_SCHUR);
     const size_t lds = (81 * (size_t)h->lseg + 9) * sizeof(double);

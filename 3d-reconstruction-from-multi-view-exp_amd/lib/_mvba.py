@@ -238,7 +238,7 @@ class HipEngine:
 
     def schur_info(self):
         i = self._info()
-        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": ("strip", "pairs", "slots")[i[3] & 0xff],
+        return {"items": i[0], "offdiag_items": i[1], "units": i[2], "kernel": ("strip", "pairs", "slots", "dense")[i[3] & 0xff],
                 "slot_rows": i[7],  # slot form: step-major rows incl. the padding rows of the bounded-skew merge
                 "slot_rounds": (i[3] >> 8) & 0xffffff, "slot_groups": i[3] >> 32}
 

@@ -575,19 +575,23 @@ def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_laun
 @pytest.mark.parametrize("n,m,p,form", [(3000, 14, 0.5, "strip"), (900, 300, 0.06, "strip"), (3000, 14, 0.5, "pairs"),
                                          (3000, 14, 0.5, "slots"), (20000, 60, 0.15, "slots"), (20000, 60, 0.15, "pairs"),
                                          (3000, 14, 0.5, "slots:3"), (20000, 60, 0.15, "slots:4"), (2500, 300, 0.04, "slots"),
-                                         (2000, 500, 0.03, "slots")])
+                                         (2000, 500, 0.03, "slots"), (3001, 12, 1.0, "dense"), (1003, 21, 1.0, "dense"), (50, 2, 1.0, "dense"),
+                                         (3001, 12, 1.0, "pairs"), (999, 21, 1.0, "slots")])
 def test_every_schur_kernel_form_matches_the_oracle(n, m, p, form, monkeypatch):
     """The three forms of K3 -- the camera-strip kernel (round 1, plain and column-segmented), the
     pair-major unit kernel (round 2) and the slot-resident kernel (round 3: one round of all camera pairs up to
     ~100 cameras; round 4: beyond that, one round per pair of camera GROUPS inside one launch -- "slots:g" forces
     g groups at a small camera count, m = 300 / 500 take 4 / 7 groups by themselves) -- each forced with
     MVBA_SCHUR, the first two in their 64-bit-offset build (MVBA_FORCE_BIG; the slot form addresses its records
-    relative to the point range instead), against the oracle's reduced system."""
+    relative to the point range instead), and the dense-visibility form (round 5: every point seen by every camera, up to 21
+    cameras -- the rank-3N update of the whole reduced matrix on the matrix cores, no index; point counts that are not a multiple
+    of its chunk, the largest and the smallest camera count, and the pair-major forms on the same full-visibility scenes),
+    against the oracle's reduced system."""
     if ":" in form:
         form, groups = form.split(":")
         monkeypatch.setenv("MVBA_SLOT_GROUPS", groups)
         monkeypatch.setenv("MVBA_POINT_ORDER", "greedy")  # (and the low-discrepancy sweep order of the points with them)
-    if form != "slots":
+    if form not in ("slots", "dense"):
         monkeypatch.setenv("MVBA_FORCE_BIG", "1")
     monkeypatch.setenv("MVBA_SCHUR", form)
     sc = make_scene(n, m, vis_p=p)
