@@ -31,6 +31,7 @@
 #include <cstring>
 #include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "mvba_common.h"
@@ -293,7 +294,7 @@ constexpr int PACE_STRIDE = 32;  // ints between two pacing counters: one 128-by
 // the path; the grid is sized for whichever of the two jobs is larger).
 __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, const double *__restrict__ PL,
                                                    double *__restrict__ PB, int *__restrict__ flag,
-                                                   double *__restrict__ Ab, long long nAb, int *__restrict__ prog, long long nprog) {
+                                                   double *__restrict__ Ab, long long nAb, int *__restrict__ prog, long long nprog, int want_r) {
   // a block's 256 points are 18 KiB of PL and 32 KiB of PB, both contiguous: moved with coalesced
   // accesses through LDS (a thread reading its own 72-byte row / writing its own 128-byte line touches
   // 64 different lines per instruction)
@@ -337,7 +338,16 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
     out[2 ^ sw] = make_double2(i12, i22);
     out[3 ^ sw] = make_double2(i00 * g0 + i01 * g1 + i02 * g2, i01 * g0 + i11 * g1 + i12 * g2);
     out[4 ^ sw] = make_double2(i02 * g0 + i12 * g1 + i22 * g2, 1.0);  // tenth double: 1 = a point (row N, the padding row, stays 0)
-    out[5 ^ sw] = out[6 ^ sw] = out[7 ^ sw] = make_double2(0.0, 0.0);
+    if (want_r) {  // the dense-visibility Schur form reads E^-1 = R R^T (R lower triangular) from the row's last three slots
+      const double r00 = sqrt(fmax(i00, 0.0)), q00 = r00 > 0.0 ? 1.0 / r00 : 0.0, r10 = i01 * q00, r20 = i02 * q00;
+      const double r11 = sqrt(fmax(i11 - r10 * r10, 0.0)), r21 = r11 > 0.0 ? (i12 - r20 * r10) / r11 : 0.0;
+      const double r22 = sqrt(fmax(i22 - r20 * r20 - r21 * r21, 0.0));
+      out[5 ^ sw] = make_double2(r00, r10);
+      out[6 ^ sw] = make_double2(r20, r11);
+      out[7 ^ sw] = make_double2(r21, r22);
+    } else {
+      out[5 ^ sw] = out[6 ^ sw] = out[7 ^ sw] = make_double2(0.0, 0.0);
+    }
   }
   __syncthreads();
   double2 *dst = reinterpret_cast<double2 *>(PB + PBS * a0);
@@ -1275,133 +1285,177 @@ constexpr int DCH = 8;             // points per chunk
 constexpr int DENSE_MAX_TILES = 12;  // 9 m <= 192: m <= 21 cameras (78 tile pairs: 20 accumulators of 4 doubles per lane)
 __device__ __forceinline__ int dense_tile_elem(int row, int col) { return ((row >> 2) << 6) | ((row & 3) << 4) | col; }  // C/D layout: col = l & 15, row = (l >> 4) + 4 reg
 
-template <int T>
-__global__ __launch_bounds__(256) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N, int m,
-                                                     double cu, double *__restrict__ part) {
-  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T, NCW = ((16 * T) / 9 + 3) / 4;
-  extern __shared__ double2 dsm[];
-  double2 *sRec = dsm;                                        // [DCH m][8]
-  double2 *sAux = sRec + (size_t)DCH * m * REC;               // [DCH m][3]: (J_X R)[:, r] for r = 0..2
-  double *sB = reinterpret_cast<double *>(sAux + (size_t)DCH * m * 3);  // [DCH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
-  double *sPB = sB + (size_t)DCH * m * 32;                    // [DCH][16]
-  double *sG = sPB + DCH * PBS;                               // [3 DCH][W]
-  int *sRow = reinterpret_cast<int *>(sG + (size_t)3 * DCH * W);  // [DCH m]: 3 x the observation's point of the chunk
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
-  int ti[NPW], tj[NPW];
+constexpr int dense_pair_ti(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a; }
+constexpr int dense_pair_tj(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a + p; }
+constexpr bool dense_tile_used(int u, int T, int wave) {  // does wave `wave` own a pair with tile u?
+  const int P = T * (T + 1) / 2;
+  for (int p = wave; p < P; p += 4)
+    if (dense_pair_ti(p, T) == u || dense_pair_tj(p, T) == u) return true;
+  return P - 1 >= 0 && (wave >= P) && (dense_pair_ti(P - 1, T) == u || dense_pair_tj(P - 1, T) == u);
+}
+// the main products of one chunk for wave WAVE: its tile pairs p = 4 q + WAVE are known at compile time, so the operand of a
+// tile is read from LDS ONCE per four rows of G and used from its register by every pair that needs it (two reads per MFMA, with
+// the tiles indexed at run time, kept the LDS half busy under the matrix cores).  (The pair -> tile arithmetic goes through class
+// templates: called as constexpr FUNCTIONS inside the unrolled loops it was evaluated at run time, with the registers indexed
+// through s_set_gpr_idx.)
+template <int T, int WAVE, int Q>
+struct DensePair {
+  static constexpr int P = T * (T + 1) / 2;
+  static constexpr int p = 4 * Q + WAVE < P ? 4 * Q + WAVE : P - 1;  // (a spare slot repeats the last pair: computed, never stored)
+  static constexpr int ti = dense_pair_ti(p, T), tj = dense_pair_tj(p, T);
+};
+template <int T, int WAVE, int U>
+struct DenseUsed { static constexpr bool v = dense_tile_used(U, T, WAVE); };
+template <int T, int WAVE, int... U>
+__device__ __forceinline__ void dense_load_tiles(const double *row, double (&t)[T], std::integer_sequence<int, U...>) {
+  ((t[U] = DenseUsed<T, WAVE, U>::v ? row[16 * U] : 0.0), ...);
+}
+template <int T, int WAVE, int... Q>
+__device__ __forceinline__ void dense_mfma_pairs(const double (&t)[T], mvba_d4 *acc, std::integer_sequence<int, Q...>) {
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[DensePair<T, WAVE, Q>::ti], t[DensePair<T, WAVE, Q>::tj], acc[Q], 0, 0, 0)), ...);
+}
+template <int T, int WAVE, int CH>
+__device__ __forceinline__ void dense_main_mfma(const double *sG, int li, int lk, mvba_d4 *acc) {
+  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T;
 #pragma unroll
-  for (int q = 0; q < NPW; ++q) {  // pair p = 4 q + wave of the upper triangle, row-major
-    int p = 4 * q + wave, a = 0;
-    if (p >= P) p = P - 1;         // (a spare slot repeats the last pair: computed, never stored)
-    while (p >= T - a) { p -= T - a; ++a; }
-    ti[q] = a; tj[q] = a + p;
+  for (int g = 0; g < 3 * CH / 4; ++g) {  // four rows of G per MFMA
+    double t[T];
+    dense_load_tiles<T, WAVE>(sG + (size_t)(4 * g + lk) * W + li, t, std::make_integer_sequence<int, T>{});
+    dense_mfma_pairs<T, WAVE>(t, acc, std::make_integer_sequence<int, NPW>{});
   }
+}
+
+// Two roles in a workgroup, one barrier per chunk: waves 0-3 multiply chunk i (main pairs and camera tiles out of the buffers of
+// parity i & 1) while the producer waves -- one per point of a chunk -- build chunk i + 1 into the other buffers, each taking its
+// point from its records (fetched into registers a chunk earlier) to the rows of G on its own, so the producers need no barrier
+// among themselves.  (With every wave doing every phase in turn -- four barriers per chunk -- the workgroups of a CU ran in
+// lockstep and the phases never overlapped: 1.55 ms at 1 M x 12 for 0.81 ms of MFMA phase; with four producer waves of two points
+// each the producers were the longer role: 1.90 ms.)
+template <int T>
+__global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N,
+                                                                    int m, double cu, double *__restrict__ part) {
+  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T, NCW = ((16 * T) / 9 + 3) / 4;
+  constexpr int CH = T <= 8 ? DCH : DCH / 2;       // points per chunk = producer waves (the double-buffered rows must fit the LDS beside each other)
+  constexpr int MMAX = (16 * T) / 9;               // cameras at most
+  constexpr int NTHR = 64 * (4 + CH);
+  extern __shared__ double2 dsm[];
+  double *sG = reinterpret_cast<double *>(dsm);                     // [2][3 CH][W]
+  double *sB = sG + (size_t)2 * 3 * CH * W;                         // [2][CH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
+  double2 *sScr = reinterpret_cast<double2 *>(sB + (size_t)2 * CH * m * 32);  // per producer wave: records [m][8], J_X R [m][3], point row [8]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const long long n_chunks = (N + CH - 1) / CH;
+  // what no phase ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
+  for (int e = threadIdx.x; e < 2 * 3 * CH * W; e += NTHR) sG[e] = 0.0;
+  for (int e = threadIdx.x; e < 2 * CH * m * 32; e += NTHR) sB[e] = 0.0;
+  __syncthreads();
+  if (wave >= 4) {
+    // ---------------- producer: point pw of every chunk of this workgroup.  (Without the staging -- a lane per (camera, column)
+    // fetching its four record slots itself -- the per-lane loads cost more than the staging saves: 1.82 against 1.40 ms.)
+    const int pw = wave - 4;
+    double2 *sR = sScr + (size_t)pw * (m * (REC + 3) + 8), *sJR = sR + (size_t)m * REC, *sP = sJR + (size_t)m * 3;
+    constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 9 + 63) / 64;
+    double2 pre[NPRE], prepb;
+    auto fetch = [&](long long ch) {               // this wave's records and point row of chunk ch (zeros past the last point)
+      const long long a = ch * CH + pw;
+      const bool live = a < N;
+      const double2 *src = rec + (size_t)min(a, N - 1) * m * REC;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int e = lane + 64 * u;
+        pre[u] = (live && e < m * REC) ? src[e] : double2{0.0, 0.0};
+      }
+      prepb = (live && lane < 8) ? reinterpret_cast<const double2 *>(PB + (size_t)min(a, N - 1) * PBS)[lane] : double2{0.0, 0.0};
+    };
+    auto build = [&](int buf) {                    // registers -> the rows of G and the camera rows of this wave's point in buffer `buf`
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int e = lane + 64 * u;
+        if (e < m * REC) sR[e] = pre[u];
+      }
+      if (lane < 8) sP[lane] = prepb;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const double *pb = reinterpret_cast<const double *>(sP);
+      double *gB = sB + ((size_t)buf * CH + pw) * m * 32;
+      // a lane per observation: J_X R (E^-1 = R R^T, R lower triangular: k_point_inv leaves it in the point row) and w = J_X E^-1 dP - e
+      if (lane < m && !(MVBA_DENSE_KO & 4)) {
+        const int o = lane;
+        const double r00 = pb[10], r10 = pb[11], r20 = pb[12], r11 = pb[13], r21 = pb[14], r22 = pb[15];
+        const double2 x0 = sR[o * REC], x1 = sR[o * REC + 1], x2 = sR[o * REC + 2], e = sR[o * REC + 7];
+        sJR[o * 3 + 0] = double2{x0.x * r00 + x1.x * r10 + x2.x * r20, x0.y * r00 + x1.y * r10 + x2.y * r20};
+        sJR[o * 3 + 1] = double2{x1.x * r11 + x2.x * r21, x1.y * r11 + x2.y * r21};
+        sJR[o * 3 + 2] = double2{x2.x * r22, x2.y * r22};
+        gB[(size_t)o * 32 + 9] = x0.x * pb[6] + x1.x * pb[7] + x2.x * pb[8] - e.x;  // (zero for a missing point: zero record, zero row)
+        gB[(size_t)o * 32 + 25] = x0.y * pb[6] + x1.y * pb[7] + x2.y * pb[8] - e.y;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      // a lane per (camera k, column j): the column of J~ (f | u, v (1 / f0) | t (-J_X) | omega) into the two camera rows, and the
+      // three rows of G at column 9 k + j
+      const double live = pb[9] * cu;  // (the point row's tenth double: 1 for a point, 0 past the end)
+      double *gG = sG + ((size_t)buf * 3 * CH + (size_t)3 * pw) * W;
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int e = lane + 64 * u, o = e / 9, cc = e - 9 * o;
+        if (e < 9 * m && !(MVBA_DENSE_KO & 2)) {
+          const double2 rv = sR[o * REC + (cc == 0 ? 3 : (cc < 6 ? (cc < 3 ? 0 : cc - 3) : cc - 2))];
+          const double sg = (cc >= 3 && cc < 6) ? -1.0 : 1.0;
+          const double jx = cc == 1 ? live : (cc == 2 ? 0.0 : sg * rv.x), jy = cc == 2 ? live : (cc == 1 ? 0.0 : sg * rv.y);
+          gB[(size_t)o * 32 + cc] = jx;
+          gB[(size_t)o * 32 + 16 + cc] = jy;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const double2 jr = sJR[o * 3 + r];
+            gG[(size_t)r * W + e] = jr.x * jx + jr.y * jy;
+          }
+        }
+      }
+    };
+    long long ch = blockIdx.x;
+    fetch(ch);
+    build(0);
+    if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
+    __syncthreads();
+    for (int b = 0; ch < n_chunks; ch += gridDim.x, b ^= 1) {
+      if (ch + gridDim.x < n_chunks) {
+        build(b ^ 1);
+        if (ch + 2 * (long long)gridDim.x < n_chunks) fetch(ch + 2 * (long long)gridDim.x);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------- consumer: tile pairs 4 q + wave of the upper triangle (row-major), cameras 4 q + wave
   mvba_d4 acc[NPW], cacc[NCW];
 #pragma unroll
   for (int q = 0; q < NPW; ++q) acc[q] = mvba_d4{0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < NCW; ++q) cacc[q] = mvba_d4{0, 0, 0, 0};
-  // what no phase below ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
-  for (int e = threadIdx.x; e < 3 * DCH * W; e += 256) sG[e] = 0.0;
-  for (int e = threadIdx.x; e < DCH * m * 32; e += 256) sB[e] = 0.0;
-  const long long n_chunks = (N + DCH - 1) / DCH;
-  // a chunk's records (DCH m x 8 double2, at most 6 per thread) and point rows (DCH x 8 double2) are fetched into registers while
-  // the previous chunk is multiplied, and put into LDS behind a barrier
-  constexpr int NPRE = (DCH * ((16 * T) / 9) * REC + 255) / 256;
-  double2 pre[NPRE], prepb;
-  auto fetch = [&](long long ch) {
-    const long long a0 = ch * DCH;
-    const int np = (int)min<long long>(DCH, N - a0), cnt = np * m * REC;
-    const double2 *src = rec + (size_t)a0 * m * REC;
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      pre[u] = e < cnt ? src[e] : double2{0.0, 0.0};
-    }
-    const int ep = threadIdx.x;
-    prepb = ep < np * (PBS / 2) ? reinterpret_cast<const double2 *>(PB + (size_t)a0 * PBS)[ep] : double2{0.0, 0.0};
-  };
-  if (blockIdx.x < n_chunks) fetch(blockIdx.x);
-  const int t9 = threadIdx.x / 9, j9 = threadIdx.x - 9 * t9;  // phase 2: thread -> (observation t9 of a pass of 28, column j9)
-  for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const long long a0 = ch * DCH;
-    const int np = (int)min<long long>(DCH, N - a0);
-    __syncthreads();  // the previous chunk's products are done
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      if (e < DCH * m * REC) sRec[e] = pre[u];
-    }
-    if (threadIdx.x < DCH * (PBS / 2)) reinterpret_cast<double2 *>(sPB)[threadIdx.x] = prepb;
-    __syncthreads();
-    if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
-#if !(MVBA_DENSE_KO & 4)
-    // phase 1, a thread per observation (past the last point of the last chunk: zero records give zero rows): J_X R with
-    // E^-1 = R R^T (R lower triangular), w = J_X E^-1 dP - e, and the two camera rows [J~ | w]
-    for (int o = threadIdx.x; o < DCH * m; o += 256) {
-      const int pa = o / m;
-      const double *pb = sPB + pa * PBS;
-      double r00 = 0.0, r10 = 0.0, r20 = 0.0, r11 = 0.0, r21 = 0.0, r22 = 0.0;
-      if (pa < np) {
-        r00 = sqrt(pb[0]);
-        const double i00 = 1.0 / r00;
-        r10 = pb[1] * i00; r20 = pb[2] * i00;
-        r11 = sqrt(pb[3] - r10 * r10);
-        r21 = (pb[4] - r20 * r10) / r11;
-        r22 = sqrt(pb[5] - r20 * r20 - r21 * r21);
-      }
-      const double2 x0 = sRec[o * REC], x1 = sRec[o * REC + 1], x2 = sRec[o * REC + 2], e = sRec[o * REC + 7];
-      sAux[o * 3 + 0] = double2{x0.x * r00 + x1.x * r10 + x2.x * r20, x0.y * r00 + x1.y * r10 + x2.y * r20};
-      sAux[o * 3 + 1] = double2{x1.x * r11 + x2.x * r21, x1.y * r11 + x2.y * r21};
-      sAux[o * 3 + 2] = double2{x2.x * r22, x2.y * r22};
-      sRow[o] = 3 * pa;
-      const double2 f = sRec[o * REC + 3], w0 = sRec[o * REC + 4], w1 = sRec[o * REC + 5], w2 = sRec[o * REC + 6];
-      const double live = pa < np ? 1.0 : 0.0;
-      double *bx = sB + (size_t)o * 32, *by = bx + 16;
-      bx[0] = f.x; by[0] = f.y;
-      bx[1] = cu * live; by[1] = 0.0;
-      bx[2] = 0.0; by[2] = cu * live;
-      bx[3] = -x0.x; by[3] = -x0.y; bx[4] = -x1.x; by[4] = -x1.y; bx[5] = -x2.x; by[5] = -x2.y;
-      bx[6] = w0.x; by[6] = w0.y; bx[7] = w1.x; by[7] = w1.y; bx[8] = w2.x; by[8] = w2.y;
-      bx[9] = (x0.x * pb[6] + x1.x * pb[7] + x2.x * pb[8] - e.x) * live;
-      by[9] = (x0.y * pb[6] + x1.y * pb[7] + x2.y * pb[8] - e.y) * live;
-    }
-#endif
-    __syncthreads();
-#if !(MVBA_DENSE_KO & 2)
-    // phase 2, a thread per (observation, column of J~): the three rows of G at column 9 k + j
-    if (t9 < 28)
-      for (int o = t9; o < DCH * m; o += 28) {
-        const int row3 = sRow[o], k = o - (row3 / 3) * m;
-        const double jx = sB[(size_t)o * 32 + j9], jy = sB[(size_t)o * 32 + 16 + j9];
-        double *g = sG + (size_t)row3 * W + 9 * k + j9;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const double2 jr = sAux[o * 3 + r];
-          g[(size_t)r * W] = jr.x * jx + jr.y * jy;
-        }
-      }
-#endif
-    __syncthreads();
+  __syncthreads();  // chunk 0 is built
+  int b = 0;
+  for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
+    const double *bG = sG + (size_t)b * 3 * CH * W, *bB = sB + (size_t)b * CH * m * 32;
 #if !(MVBA_DENSE_KO & 1)
-#pragma unroll
-    for (int g = 0; g < 3 * DCH / 4; ++g) {  // four rows of G per MFMA
-      const double *row = sG + (size_t)(4 * g + lk) * W + li;
-#pragma unroll
-      for (int q = 0; q < NPW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ti[q]], row[16 * tj[q]], acc[q], 0, 0, 0);
+    switch (wave) {  // (uniform)
+      case 0: dense_main_mfma<T, 0, CH>(bG, li, lk, acc); break;
+      case 1: dense_main_mfma<T, 1, CH>(bG, li, lk, acc); break;
+      case 2: dense_main_mfma<T, 2, CH>(bG, li, lk, acc); break;
+      default: dense_main_mfma<T, 3, CH>(bG, li, lk, acc); break;
     }
 #endif
 #if !(MVBA_DENSE_KO & 8)
 #pragma unroll
-    for (int g = 0; g < DCH / 2; ++g) {  // the per-camera tiles: rows (point 2 g, x), (2 g, y), (2 g + 1, x), (2 g + 1, y)
+    for (int g = 0; g < CH / 2; ++g) {  // the per-camera tiles: rows (point 2 g, x), (2 g, y), (2 g + 1, x), (2 g + 1, y)
       const int pa = 2 * g + (lk >> 1), d = lk & 1;
 #pragma unroll
       for (int q = 0; q < NCW; ++q) {
         const int k = min(4 * q + wave, m - 1);
-        const double v = sB[(size_t)(pa * m + k) * 32 + 16 * d + li];
+        const double v = bB[(size_t)(pa * m + k) * 32 + 16 * d + li];
         cacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, cacc[q], 0, 0, 0);
       }
     }
 #endif
+    __syncthreads();  // this chunk's buffers may be rebuilt, the next chunk's are complete
   }
   double *out = part + (size_t)blockIdx.x * (P + m) * 256;
 #pragma unroll
@@ -4225,8 +4279,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemset(h->d_flag, 0, sizeof(int)));
   if (h->schur_mode == SCHUR_DENSE) {  // partial tiles of k_schur_dense: (tile pairs + one per camera) x 256 doubles per workgroup
     const int T = (9 * m + 15) / 16;
+    int n_cu_dense = 256;
+    hipDeviceGetAttribute(&n_cu_dense, hipDeviceAttributeMultiprocessorCount, h->device);
     h->dense_tiles = T * (T + 1) / 2 + m;
-    h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + DCH - 1) / DCH, 1024));
+    h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + (T <= 8 ? DCH : DCH / 2) - 1) / (T <= 8 ? DCH : DCH / 2), n_cu_dense));  // one workgroup (eight waves, ~110 KB of LDS) per CU
     TRY(dmalloc(&h->d_dense_part, (size_t)h->dense_blocks * h->dense_tiles * 256));
   }
   if (h->use_pairs) {
@@ -4449,7 +4505,8 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const long long nAb = (long long)(nA + n9);
     const unsigned grid = (unsigned)std::max<long long>((h->N + 255) / 256, std::min<long long>((nAb + 1023) / 1024, 4096));
     hipLaunchKernelGGL(k_point_inv, dim3(std::max(grid, 1u)), dim3(256), 0, h->stream, h->N, c, h->d_PL, h->d_PB, h->d_flag,
-                       h->d_Ab, nAb, h->d_prog, h->slot_pace ? (long long)h->slot_rounds * h->slot_nR * h->slot_nseg * PACE_STRIDE : 0LL);
+                       h->d_Ab, nAb, h->d_prog, h->slot_pace ? (long long)h->slot_rounds * h->slot_nR * h->slot_nseg * PACE_STRIDE : 0LL,
+                       h->schur_mode == SCHUR_DENSE ? 1 : 0);
   }
   if (h->use_pairs) {
     Timed t(h, MVBA_K_SCHUR);
@@ -4472,11 +4529,11 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   } else if (h->schur_mode == SCHUR_DENSE) {
     Timed t(h, MVBA_K_SCHUR);
     const int T = (9 * m + 15) / 16;
-    const size_t lds = sizeof(double2) * (size_t)DCH * m * (REC + 3) + sizeof(double) * ((size_t)DCH * m * 32 + (size_t)DCH * PBS + (size_t)3 * DCH * 16 * T) +
-                       sizeof(int) * (size_t)DCH * m;
+    const int CH = T <= 8 ? DCH : DCH / 2;
+    const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * (REC + 3) + 8);
     auto launch = [&](auto kern) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(256), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
+      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * (4 + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
                          1.0 / h->f0, h->d_dense_part);
     };
     switch (T) {

@@ -146,6 +146,16 @@ def schur_roofline(info, n_obs, k3_ms, n_cu):
     (`traffic` = 12-13 x the algorithmic bytes at 500 cameras)."""
     k3_bytes = 192 * n_obs
     k3_ach = k3_bytes / (k3_ms * 1e-3) / 1e9
+    if info["kernel"] == "dense":  # full visibility, up to 21 cameras: one rank-3N update of the reduced matrix on the f64 matrix cores
+        m9 = 9 * info["n_cams"]
+        tiles = (m9 + 15) // 16
+        mfmas = info["n_points"] * (0.75 * tiles * (tiles + 1) / 2 + info["n_cams"] / 2)  # four rows of G per MFMA; two points per camera tile
+        mfma_tflops = mfmas * 2048 / (k3_ms * 1e-3) / 1e12
+        return {"kernel": "k_schur_dense (K3)", "bound": "mfma", "achieved": mfma_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": mfma_tflops / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                "bound_note": "v_mfma_f64_16x16x4 issued (padding of the 9 m columns to 16-column tiles included) x 2048 flop against the "
+                              "78.6 TFLOP/s of the f64 matrix cores; the records (128 B/observation) are streamed once",
+                "algorithmic_bytes_per_launch": 128 * n_obs, "hbm_GBs": 128 * n_obs / (k3_ms * 1e-3) / 1e9, "avg_launch_ms": k3_ms}
     k3_name = {"strip": "k_schur_strip", "pairs": "k_schur_pairs", "slots": "k_schur_slots"}[info["kernel"]]
     k3_traffic, k3_src = pmc_traffic(k3_name, n_obs)
     gather = info["items"] * (112 + 48 + 12) + info["offdiag_items"] * 112
@@ -676,6 +686,7 @@ def main():
             n_cu = int(torch.cuda.get_device_properties(device).multi_processor_count)
         except Exception:  # noqa: BLE001
             pass
+        info.update(n_cams=n_cams, n_points=sc.n_points)
         roof_k3 = schur_roofline(info, sc.n_obs, k3_ms, n_cu)
         roof_k1 = {"kernel": "k_resid_jac (K1+K2)", "bound": "hbm", "achieved": k1_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": k1_ach / HBM_PEAK_GBS, "traffic": k1_traffic, "traffic_source": k1_src,
