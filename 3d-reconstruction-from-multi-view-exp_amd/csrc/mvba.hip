@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
   extern __shared__ double2 dsm[];
   double *sG = reinterpret_cast<double *>(dsm);                     // [2][3 CH][W]
   double *sB = sG + (size_t)2 * 3 * CH * W;                         // [2][CH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
-  double2 *sScr = reinterpret_cast<double2 *>(sB + (size_t)2 * CH * m * 32);  // per producer wave: records [m][8], J_X R [m][3], point row [8]
+  double2 *sScr = reinterpret_cast<double2 *>(sB + (size_t)2 * CH * m * 32);  // per producer wave: records [m][8], point row [8]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const long long n_chunks = (N + CH - 1) / CH;
   // what no phase ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
@@ -1352,8 +1352,8 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
     // ---------------- producer: point pw of every chunk of this workgroup.  (Without the staging -- a lane per (camera, column)
     // fetching its four record slots itself -- the per-lane loads cost more than the staging saves: 1.82 against 1.40 ms.)
     const int pw = wave - 4;
-    double2 *sR = sScr + (size_t)pw * (m * (REC + 3) + 8), *sJR = sR + (size_t)m * REC, *sP = sJR + (size_t)m * 3;
-    constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 9 + 63) / 64;
+    double2 *sR = sScr + (size_t)pw * (m * REC + 8), *sP = sR + (size_t)m * REC;
+    constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 10 + 63) / 64;
     double2 pre[NPRE], prepb;
     auto fetch = [&](long long ch) {               // this wave's records and point row of chunk ch (zeros past the last point)
       const long long a = ch * CH + pw;
@@ -1375,38 +1375,33 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
       if (lane < 8) sP[lane] = prepb;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      // point row: E^-1 (6) | E^-1 dP (3) | 1 | R lower triangular (r00 r10 r20 r11 r21 r22: k_point_inv), the same for every lane
       const double *pb = reinterpret_cast<const double *>(sP);
+      const double d0 = pb[6], d1 = pb[7], d2 = pb[8], live = pb[9] * cu;
+      const double r00 = pb[10], r10 = pb[11], r20 = pb[12], r11 = pb[13], r21 = pb[14], r22 = pb[15];
       double *gB = sB + ((size_t)buf * CH + pw) * m * 32;
-      // a lane per observation: J_X R (E^-1 = R R^T, R lower triangular: k_point_inv leaves it in the point row) and w = J_X E^-1 dP - e
-      if (lane < m && !(MVBA_DENSE_KO & 4)) {
-        const int o = lane;
-        const double r00 = pb[10], r10 = pb[11], r20 = pb[12], r11 = pb[13], r21 = pb[14], r22 = pb[15];
-        const double2 x0 = sR[o * REC], x1 = sR[o * REC + 1], x2 = sR[o * REC + 2], e = sR[o * REC + 7];
-        sJR[o * 3 + 0] = double2{x0.x * r00 + x1.x * r10 + x2.x * r20, x0.y * r00 + x1.y * r10 + x2.y * r20};
-        sJR[o * 3 + 1] = double2{x1.x * r11 + x2.x * r21, x1.y * r11 + x2.y * r21};
-        sJR[o * 3 + 2] = double2{x2.x * r22, x2.y * r22};
-        gB[(size_t)o * 32 + 9] = x0.x * pb[6] + x1.x * pb[7] + x2.x * pb[8] - e.x;  // (zero for a missing point: zero record, zero row)
-        gB[(size_t)o * 32 + 25] = x0.y * pb[6] + x1.y * pb[7] + x2.y * pb[8] - e.y;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      // a lane per (camera k, column j): the column of J~ (f | u, v (1 / f0) | t (-J_X) | omega) into the two camera rows, and the
-      // three rows of G at column 9 k + j
-      const double live = pb[9] * cu;  // (the point row's tenth double: 1 for a point, 0 past the end)
       double *gG = sG + ((size_t)buf * 3 * CH + (size_t)3 * pw) * W;
+      // a lane per (camera k, column j <= 9): column j of J~ (f | u, v (1 / f0) | t (-J_X) | omega) into the two camera rows and
+      // G[r][9 k + j] = (J_X R)[:, r] . J~[:, j] (E^-1 = R R^T); j = 9: w = J_X E^-1 dP - e, the tenth column of the camera rows
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
-        const int e = lane + 64 * u, o = e / 9, cc = e - 9 * o;
-        if (e < 9 * m && !(MVBA_DENSE_KO & 2)) {
-          const double2 rv = sR[o * REC + (cc == 0 ? 3 : (cc < 6 ? (cc < 3 ? 0 : cc - 3) : cc - 2))];
-          const double sg = (cc >= 3 && cc < 6) ? -1.0 : 1.0;
-          const double jx = cc == 1 ? live : (cc == 2 ? 0.0 : sg * rv.x), jy = cc == 2 ? live : (cc == 1 ? 0.0 : sg * rv.y);
-          gB[(size_t)o * 32 + cc] = jx;
-          gB[(size_t)o * 32 + 16 + cc] = jy;
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const double2 jr = sJR[o * 3 + r];
-            gG[(size_t)r * W + e] = jr.x * jx + jr.y * jy;
+        const int e = lane + 64 * u, k = e / 10, j = e - 10 * k;
+        if (e < 10 * m && !(MVBA_DENSE_KO & 2)) {
+          const double2 *r = sR + (size_t)k * REC;
+          const double2 x0 = r[0], x1 = r[1], x2 = r[2];
+          const double2 cv = r[j == 0 ? 3 : (j < 6 ? (j < 3 ? 0 : j - 3) : (j < 9 ? j - 2 : 7))];
+          if (j == 9) {
+            gB[(size_t)k * 32 + 9] = x0.x * d0 + x1.x * d1 + x2.x * d2 - cv.x;
+            gB[(size_t)k * 32 + 25] = x0.y * d0 + x1.y * d1 + x2.y * d2 - cv.y;
+          } else {
+            const double sg = (j >= 3 && j < 6) ? -1.0 : 1.0;
+            const double jx = j == 1 ? live : (j == 2 ? 0.0 : sg * cv.x), jy = j == 2 ? live : (j == 1 ? 0.0 : sg * cv.y);
+            gB[(size_t)k * 32 + j] = jx;
+            gB[(size_t)k * 32 + 16 + j] = jy;
+            double *g = gG + 9 * k + j;
+            g[0] = (x0.x * r00 + x1.x * r10 + x2.x * r20) * jx + (x0.y * r00 + x1.y * r10 + x2.y * r20) * jy;
+            g[W] = (x1.x * r11 + x2.x * r21) * jx + (x1.y * r11 + x2.y * r21) * jy;
+            g[2 * W] = (x2.x * r22) * jx + (x2.y * r22) * jy;
           }
         }
       }
@@ -4530,7 +4525,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_SCHUR);
     const int T = (9 * m + 15) / 16;
     const int CH = T <= 8 ? DCH : DCH / 2;
-    const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * (REC + 3) + 8);
+    const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8);
     auto launch = [&](auto kern) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * (4 + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
