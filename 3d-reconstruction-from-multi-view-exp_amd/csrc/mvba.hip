@@ -1287,21 +1287,23 @@ __device__ __forceinline__ int dense_tile_elem(int row, int col) { return ((row 
 
 constexpr int dense_pair_ti(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a; }
 constexpr int dense_pair_tj(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a + p; }
-constexpr bool dense_tile_used(int u, int T, int wave) {  // does wave `wave` own a pair with tile u?
-  const int P = T * (T + 1) / 2;
-  for (int p = wave; p < P; p += 4)
+constexpr int dense_consumers(int T) { return T <= 8 ? 4 : 8; }  // consumer waves: at most ~10 tile pairs (40 accumulator doubles) each
+constexpr bool dense_tile_used(int u, int T, int wave) {  // does consumer wave `wave` own a pair with tile u?
+  const int P = T * (T + 1) / 2, NC = dense_consumers(T);
+  for (int p = wave; p < P; p += NC)
     if (dense_pair_ti(p, T) == u || dense_pair_tj(p, T) == u) return true;
-  return P - 1 >= 0 && (wave >= P) && (dense_pair_ti(P - 1, T) == u || dense_pair_tj(P - 1, T) == u);
+  // (its spare slots repeat the last pair)
+  return (P + NC - 1) / NC * NC - NC + wave >= P && (dense_pair_ti(P - 1, T) == u || dense_pair_tj(P - 1, T) == u);
 }
-// the main products of one chunk for wave WAVE: its tile pairs p = 4 q + WAVE are known at compile time, so the operand of a
+// the main products of one chunk for consumer wave WAVE: its tile pairs p = NC q + WAVE are known at compile time, so the operand of a
 // tile is read from LDS ONCE per four rows of G and used from its register by every pair that needs it (two reads per MFMA, with
 // the tiles indexed at run time, kept the LDS half busy under the matrix cores).  (The pair -> tile arithmetic goes through class
 // templates: called as constexpr FUNCTIONS inside the unrolled loops it was evaluated at run time, with the registers indexed
 // through s_set_gpr_idx.)
 template <int T, int WAVE, int Q>
 struct DensePair {
-  static constexpr int P = T * (T + 1) / 2;
-  static constexpr int p = 4 * Q + WAVE < P ? 4 * Q + WAVE : P - 1;  // (a spare slot repeats the last pair: computed, never stored)
+  static constexpr int P = T * (T + 1) / 2, NC = dense_consumers(T);
+  static constexpr int p = NC * Q + WAVE < P ? NC * Q + WAVE : P - 1;  // (a spare slot repeats the last pair: computed, never stored)
   static constexpr int ti = dense_pair_ti(p, T), tj = dense_pair_tj(p, T);
 };
 template <int T, int WAVE, int U>
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void dense_mfma_pairs(const double (&t)[T], mvba_d4 *
 }
 template <int T, int WAVE, int CH>
 __device__ __forceinline__ void dense_main_mfma(const double *sG, int li, int lk, mvba_d4 *acc) {
-  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T;
+  constexpr int P = T * (T + 1) / 2, NC = dense_consumers(T), NPW = (P + NC - 1) / NC, W = 16 * T;
 #pragma unroll
   for (int g = 0; g < 3 * CH / 4; ++g) {  // four rows of G per MFMA
     double t[T];
@@ -1332,12 +1334,13 @@ __device__ __forceinline__ void dense_main_mfma(const double *sG, int li, int lk
 // lockstep and the phases never overlapped: 1.55 ms at 1 M x 12 for 0.81 ms of MFMA phase; with four producer waves of two points
 // each the producers were the longer role: 1.90 ms.)
 template <int T>
-__global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N,
-                                                                    int m, double cu, double *__restrict__ part) {
-  constexpr int P = T * (T + 1) / 2, NPW = (P + 3) / 4, W = 16 * T, NCW = ((16 * T) / 9 + 3) / 4;
+__global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N,
+                                                     int m, double cu, double *__restrict__ part) {
+  constexpr int NC = dense_consumers(T);           // consumer waves (4 + 8 producers up to 8 tiles, 8 + 4 beyond)
+  constexpr int P = T * (T + 1) / 2, NPW = (P + NC - 1) / NC, W = 16 * T, NCW = ((16 * T) / 9 + NC - 1) / NC;
   constexpr int CH = T <= 8 ? DCH : DCH / 2;       // points per chunk = producer waves (the double-buffered rows must fit the LDS beside each other)
   constexpr int MMAX = (16 * T) / 9;               // cameras at most
-  constexpr int NTHR = 64 * (4 + CH);
+  constexpr int NTHR = 64 * (NC + CH);
   extern __shared__ double2 dsm[];
   double *sG = reinterpret_cast<double *>(dsm);                     // [2][3 CH][W]
   double *sB = sG + (size_t)2 * 3 * CH * W;                         // [2][CH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
@@ -1348,10 +1351,10 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
   for (int e = threadIdx.x; e < 2 * 3 * CH * W; e += NTHR) sG[e] = 0.0;
   for (int e = threadIdx.x; e < 2 * CH * m * 32; e += NTHR) sB[e] = 0.0;
   __syncthreads();
-  if (wave >= 4) {
+  if (wave >= NC) {
     // ---------------- producer: point pw of every chunk of this workgroup.  (Without the staging -- a lane per (camera, column)
     // fetching its four record slots itself -- the per-lane loads cost more than the staging saves: 1.82 against 1.40 ms.)
-    const int pw = wave - 4;
+    const int pw = wave - NC;
     double2 *sR = sScr + (size_t)pw * (m * REC + 8), *sP = sR + (size_t)m * REC;
     constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 10 + 63) / 64;
     double2 pre[NPRE], prepb;
@@ -1420,7 +1423,7 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
     }
     return;
   }
-  // ---------------- consumer: tile pairs 4 q + wave of the upper triangle (row-major), cameras 4 q + wave
+  // ---------------- consumer: tile pairs NC q + wave of the upper triangle (row-major), cameras NC q + wave
   mvba_d4 acc[NPW], cacc[NCW];
 #pragma unroll
   for (int q = 0; q < NPW; ++q) acc[q] = mvba_d4{0, 0, 0, 0};
@@ -1435,7 +1438,11 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
       case 0: dense_main_mfma<T, 0, CH>(bG, li, lk, acc); break;
       case 1: dense_main_mfma<T, 1, CH>(bG, li, lk, acc); break;
       case 2: dense_main_mfma<T, 2, CH>(bG, li, lk, acc); break;
-      default: dense_main_mfma<T, 3, CH>(bG, li, lk, acc); break;
+      case 3: dense_main_mfma<T, 3, CH>(bG, li, lk, acc); break;
+      case 4: dense_main_mfma<T, 4 % NC, CH>(bG, li, lk, acc); break;  // (cases 4..7 exist with eight consumers only)
+      case 5: dense_main_mfma<T, 5 % NC, CH>(bG, li, lk, acc); break;
+      case 6: dense_main_mfma<T, 6 % NC, CH>(bG, li, lk, acc); break;
+      default: dense_main_mfma<T, 7 % NC, CH>(bG, li, lk, acc); break;
     }
 #endif
 #if !(MVBA_DENSE_KO & 8)
@@ -1444,7 +1451,7 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
       const int pa = 2 * g + (lk >> 1), d = lk & 1;
 #pragma unroll
       for (int q = 0; q < NCW; ++q) {
-        const int k = min(4 * q + wave, m - 1);
+        const int k = min(NC * q + wave, m - 1);
         const double v = bB[(size_t)(pa * m + k) * 32 + 16 * d + li];
         cacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, cacc[q], 0, 0, 0);
       }
@@ -1455,14 +1462,14 @@ __global__ __launch_bounds__(T <= 8 ? 768 : 512) void k_schur_dense(const double
   double *out = part + (size_t)blockIdx.x * (P + m) * 256;
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
-    const int p = 4 * q + wave;
+    const int p = NC * q + wave;
     if (p < P)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(size_t)p * 256 + r * 64 + lane] = acc[q][r];
   }
 #pragma unroll
   for (int q = 0; q < NCW; ++q) {
-    const int k = 4 * q + wave;
+    const int k = NC * q + wave;
     if (k < m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(size_t)(P + k) * 256 + r * 64 + lane] = cacc[q][r];
@@ -4528,7 +4535,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8);
     auto launch = [&](auto kern) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * (4 + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
+      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
                          1.0 / h->f0, h->d_dense_part);
     };
     switch (T) {
