@@ -187,6 +187,11 @@ def test_bench_round5_helpers_cores_allreduce_model_and_shard_roofline(monkeypat
     slot = bench.schur_roofline({"kernel": "slots", "items": 59_501_226, "offdiag_items": 49_499_384, "units": 47_600, "slot_rows": 66_863_118},
                                 10_001_842, 1.58, 256)
     assert slot["bound"] == "l2_gather" and slot["gather"]["row_gathers_per_launch"] == 3 * 66_863_118
+    # the dense-visibility form is priced against the f64 matrix cores: 0.75 MFMAs per tile pair and point + half a one per camera
+    dense = bench.schur_roofline({"kernel": "dense", "items": 0, "offdiag_items": 0, "units": 0, "slot_rows": 0, "n_cams": 12, "n_points": 1_000_000},
+                                 12_000_000, 1.31, 256)
+    assert dense["bound"] == "mfma" and dense["unit"] == "TFLOP/s" and dense["traffic"] is None
+    assert dense["achieved"] == pytest.approx(1e6 * (0.75 * 28 + 6) * 2048 / 1.31e-3 / 1e12) and dense["frac"] == pytest.approx(dense["achieved"] / 78.6)
 
 
 def test_full_visibility_fast_paths_equal_the_general_ones():
