@@ -3183,6 +3183,7 @@ struct mvba_handle {
   double *d_partial = nullptr;
   double *d_dense_part = nullptr;     // SCHUR_DENSE: partial tiles per workgroup
   int dense_blocks = 0, dense_tiles = 0;
+  bool dense_attr_set = false;
   // state: [cur] committed, [1-cur] trial
   double *d_X[2] = {nullptr, nullptr}, *d_cam15[2] = {nullptr, nullptr};
   int cur = 0;
@@ -4534,7 +4535,10 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int CH = T <= 8 ? DCH : DCH / 2;
     const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8);
     auto launch = [&](auto kern) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (!h->dense_attr_set) {  // (once per engine: m, hence the instantiation and its LDS, never change)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        h->dense_attr_set = true;
+      }
       hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
                          1.0 / h->f0, h->d_dense_part);
     };
