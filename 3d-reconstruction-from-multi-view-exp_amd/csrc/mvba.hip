@@ -4535,8 +4535,10 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     const int CH = T <= 8 ? DCH : DCH / 2;
     const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8);
     auto launch = [&](auto kern) {
-      if (!h->dense_attr_set) {  // (once per engine: m, hence the instantiation and its LDS, never change)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (!h->dense_attr_set) {  // (once per engine; the limit of the INSTANTIATION -- its largest camera count -- so that engines with other m share it)
+        const int mm = 16 * T / 9;
+        const size_t lds_max = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * mm * 32) + sizeof(double2) * CH * ((size_t)mm * REC + 8);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         h->dense_attr_set = true;
       }
       hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,

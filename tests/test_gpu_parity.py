@@ -957,3 +957,17 @@ def test_tiny_scenes_fewer_points_than_point_ranges(n, m, p):
     np.testing.assert_allclose(eng.debug_read("b_full"), b, rtol=0, atol=1e-9 * max(np.abs(b).max(), 1e-300))
     if np.isfinite(E1o) and np.linalg.cond(g.A) < 1e12:
         assert E1 == pytest.approx(E1o, rel=1e-6, abs=1e-12)
+
+
+def test_dense_form_engines_with_different_camera_counts_alive_together():
+    """Two engines whose camera counts share one instantiation of k_schur_dense (11 and 12 cameras: 7 tiles) but need different amounts
+    of LDS, stepping alternately: the kernel's LDS limit is the instantiation's, not the first engine's."""
+    engines = []
+    for m in (12, 11):
+        sc = make_scene(900, m, vis_p=1.0)
+        ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t, axis=sc.axis)
+        assert ba._engine.schur_info()["kernel"] == "dense"
+        ba._engine.linearize()
+        engines.append(ba._engine)
+    costs = [[e.try_step(1e-3) for e in engines] for _ in range(3)]
+    assert np.all(np.isfinite(costs)) and costs[0] == costs[1] == costs[2]
