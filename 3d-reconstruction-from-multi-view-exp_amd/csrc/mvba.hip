@@ -338,13 +338,19 @@ __global__ __launch_bounds__(256) void k_point_inv(long long npts, double c, con
     out[2 ^ sw] = make_double2(i12, i22);
     out[3 ^ sw] = make_double2(i00 * g0 + i01 * g1 + i02 * g2, i01 * g0 + i11 * g1 + i12 * g2);
     out[4 ^ sw] = make_double2(i02 * g0 + i12 * g1 + i22 * g2, 1.0);  // tenth double: 1 = a point (row N, the padding row, stays 0)
-    if (want_r) {  // the dense-visibility Schur form reads E^-1 = R R^T (R lower triangular) from the row's last three slots
-      const double r00 = sqrt(fmax(i00, 0.0)), q00 = r00 > 0.0 ? 1.0 / r00 : 0.0, r10 = i01 * q00, r20 = i02 * q00;
-      const double r11 = sqrt(fmax(i11 - r10 * r10, 0.0)), r21 = r11 > 0.0 ? (i12 - r20 * r10) / r11 : 0.0;
-      const double r22 = sqrt(fmax(i22 - r20 * r20 - r21 * r21, 0.0));
-      out[5 ^ sw] = make_double2(r00, r10);
-      out[6 ^ sw] = make_double2(r20, r11);
-      out[7 ^ sw] = make_double2(r21, r22);
+    if (want_r) {
+      // the dense-visibility Schur form reads E^-1 = R S R^T from the row's last three slots: R lower triangular, S = diag(+-1) --
+      // L D L^T with |D|^1/2 folded into the columns; S = I for the positive definite inverse of every LM step, but the damped
+      // blocks of a NEGATIVE damping factor (the LU-path test; np.linalg.solve takes any system) are indefinite.  The signs ride in
+      // the tenth double: 1 + (d0 < 0) + 2 (d1 < 0) + 4 (d2 < 0)  (nobody else reads it in this mode)
+      const double d0 = i00, q0 = d0 != 0.0 ? 1.0 / d0 : 0.0, l10 = i01 * q0, l20 = i02 * q0;
+      const double d1 = i11 - l10 * i01, q1 = d1 != 0.0 ? 1.0 / d1 : 0.0, l21 = (i12 - l20 * i01) * q1;
+      const double d2 = i22 - l20 * i02 - l21 * l21 * d1;
+      const double a0 = sqrt(fabs(d0)), a1 = sqrt(fabs(d1)), a2 = sqrt(fabs(d2));
+      out[4 ^ sw].y = 1.0 + (d0 < 0.0 ? 1.0 : 0.0) + (d1 < 0.0 ? 2.0 : 0.0) + (d2 < 0.0 ? 4.0 : 0.0);
+      out[5 ^ sw] = make_double2(a0, l10 * a0);
+      out[6 ^ sw] = make_double2(l20 * a0, a1);
+      out[7 ^ sw] = make_double2(l21 * a1, a2);
     } else {
       out[5 ^ sw] = out[6 ^ sw] = out[7 ^ sw] = make_double2(0.0, 0.0);
     }
@@ -1313,17 +1319,20 @@ __device__ __forceinline__ void dense_load_tiles(const double *row, double (&t)[
   ((t[U] = DenseUsed<T, WAVE, U>::v ? row[16 * U] : 0.0), ...);
 }
 template <int T, int WAVE, int... Q>
-__device__ __forceinline__ void dense_mfma_pairs(const double (&t)[T], mvba_d4 *acc, std::integer_sequence<int, Q...>) {
-  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[DensePair<T, WAVE, Q>::ti], t[DensePair<T, WAVE, Q>::tj], acc[Q], 0, 0, 0)), ...);
+__device__ __forceinline__ void dense_mfma_pairs(const double (&ts)[T], const double (&t)[T], mvba_d4 *acc, std::integer_sequence<int, Q...>) {
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ts[DensePair<T, WAVE, Q>::ti], t[DensePair<T, WAVE, Q>::tj], acc[Q], 0, 0, 0)), ...);
 }
 template <int T, int WAVE, int CH>
-__device__ __forceinline__ void dense_main_mfma(const double *sG, int li, int lk, mvba_d4 *acc) {
+__device__ __forceinline__ void dense_main_mfma(const double *sG, const double *sSgn, int li, int lk, mvba_d4 *acc) {
   constexpr int P = T * (T + 1) / 2, NC = dense_consumers(T), NPW = (P + NC - 1) / NC, W = 16 * T;
 #pragma unroll
-  for (int g = 0; g < 3 * CH / 4; ++g) {  // four rows of G per MFMA
-    double t[T];
+  for (int g = 0; g < 3 * CH / 4; ++g) {  // four rows of G per MFMA: sum_r s_r g_r^T g_r (s = +-1: E^-1 = R S R^T), the sign on the left operand
+    double t[T], ts[T];
     dense_load_tiles<T, WAVE>(sG + (size_t)(4 * g + lk) * W + li, t, std::make_integer_sequence<int, T>{});
-    dense_mfma_pairs<T, WAVE>(t, acc, std::make_integer_sequence<int, NPW>{});
+    const double sg = sSgn[4 * g + lk];
+#pragma unroll
+    for (int u = 0; u < T; ++u) ts[u] = t[u] * sg;
+    dense_mfma_pairs<T, WAVE>(ts, t, acc, std::make_integer_sequence<int, NPW>{});
   }
 }
 
@@ -1333,9 +1342,9 @@ __device__ __forceinline__ void dense_main_mfma(const double *sG, int li, int lk
 // among themselves.  (With every wave doing every phase in turn -- four barriers per chunk -- the workgroups of a CU ran in
 // lockstep and the phases never overlapped: 1.55 ms at 1 M x 12 for 0.81 ms of MFMA phase; with four producer waves of two points
 // each the producers were the longer role: 1.90 ms.)
-template <int T>
-__global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, long long N,
-                                                     int m, double cu, double *__restrict__ part) {
+template <int T, bool TABLE>  // TABLE: the records of a point through obs_of (missing observations), otherwise one contiguous range
+__global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
+                                                     long long N, int m, double cu, double *__restrict__ part) {
   constexpr int NC = dense_consumers(T);           // consumer waves (4 + 8 producers up to 8 tiles, 8 + 4 beyond)
   constexpr int P = T * (T + 1) / 2, NPW = (P + NC - 1) / NC, W = 16 * T, NCW = ((16 * T) / 9 + NC - 1) / NC;
   constexpr int CH = T <= 8 ? DCH : DCH / 2;       // points per chunk = producer waves (the double-buffered rows must fit the LDS beside each other)
@@ -1345,6 +1354,8 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
   double *sG = reinterpret_cast<double *>(dsm);                     // [2][3 CH][W]
   double *sB = sG + (size_t)2 * 3 * CH * W;                         // [2][CH m][2][16]: rows x, y of [J~ (9) | w | 0 ...]
   double2 *sScr = reinterpret_cast<double2 *>(sB + (size_t)2 * CH * m * 32);  // per producer wave: records [m][8], point row [8]
+  double *sFlag = reinterpret_cast<double *>(sScr + (size_t)CH * (m * REC + 8));  // per producer wave: [m] 1 for an observation, 0 for a missing one
+  double *sSgn = sFlag + (size_t)CH * m;                            // [2][3 CH]: the signs of the rows of G
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const long long n_chunks = (N + CH - 1) / CH;
   // what no phase ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
@@ -1358,14 +1369,33 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
     double2 *sR = sScr + (size_t)pw * (m * REC + 8), *sP = sR + (size_t)m * REC;
     constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 10 + 63) / 64;
     double2 pre[NPRE], prepb;
-    auto fetch = [&](long long ch) {               // this wave's records and point row of chunk ch (zeros past the last point)
+    int oid[NPRE], oid_next[NPRE];                 // (obs_of != nullptr) the observations of this chunk's / the next chunk's point
+    double *sF = sFlag + (size_t)pw * m;
+    auto fetch_ids = [&](long long ch) {           // the table row of chunk ch's point (one entry per record: eight lanes share it)
       const long long a = ch * CH + pw;
-      const bool live = a < N;
-      const double2 *src = rec + (size_t)min(a, N - 1) * m * REC;
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int e = lane + 64 * u;
-        pre[u] = (live && e < m * REC) ? src[e] : double2{0.0, 0.0};
+        oid_next[u] = (a < N && e < m * REC) ? obs_of[(size_t)a * m + (e >> 3)] : -1;
+      }
+    };
+    auto fetch = [&](long long ch) {               // this wave's records and point row of chunk ch (zeros past the last point)
+      const long long a = ch * CH + pw;
+      const bool live = a < N;
+      if (TABLE) {                                 // through the table read a chunk earlier: a missing observation is a zero record
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+          oid[u] = oid_next[u];
+          pre[u] = oid[u] >= 0 ? rec[(size_t)oid[u] * REC + ((lane + 64 * u) & 7)] : double2{0.0, 0.0};
+        }
+      } else {
+        const double2 *src = rec + (size_t)min(a, N - 1) * m * REC;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+          const int e = lane + 64 * u;
+          pre[u] = (live && e < m * REC) ? src[e] : double2{0.0, 0.0};
+          oid[u] = live ? 0 : -1;
+        }
       }
       prepb = (live && lane < 8) ? reinterpret_cast<const double2 *>(PB + (size_t)min(a, N - 1) * PBS)[lane] : double2{0.0, 0.0};
     };
@@ -1374,16 +1404,18 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
       for (int u = 0; u < NPRE; ++u) {
         const int e = lane + 64 * u;
         if (e < m * REC) sR[e] = pre[u];
+        if (e < m * REC && (e & 7) == 0) sF[e >> 3] = oid[u] >= 0 ? 1.0 : 0.0;
       }
       if (lane < 8) sP[lane] = prepb;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      // point row: E^-1 (6) | E^-1 dP (3) | 1 | R lower triangular (r00 r10 r20 r11 r21 r22: k_point_inv), the same for every lane
+      // point row: E^-1 (6) | E^-1 dP (3) | sign code | R lower triangular (r00 r10 r20 r11 r21 r22) of E^-1 = R S R^T (k_point_inv), the same for every lane
       const double *pb = reinterpret_cast<const double *>(sP);
-      const double d0 = pb[6], d1 = pb[7], d2 = pb[8], live = pb[9] * cu;
+      const double d0 = pb[6], d1 = pb[7], d2 = pb[8];
       const double r00 = pb[10], r10 = pb[11], r20 = pb[12], r11 = pb[13], r21 = pb[14], r22 = pb[15];
       double *gB = sB + ((size_t)buf * CH + pw) * m * 32;
       double *gG = sG + ((size_t)buf * 3 * CH + (size_t)3 * pw) * W;
+      if (lane < 3) sSgn[(size_t)buf * 3 * CH + 3 * pw + lane] = (((int)pb[9] - 1) >> lane) & 1 ? -1.0 : 1.0;
       // a lane per (camera k, column j <= 9): column j of J~ (f | u, v (1 / f0) | t (-J_X) | omega) into the two camera rows and
       // G[r][9 k + j] = (J_X R)[:, r] . J~[:, j] (E^-1 = R R^T); j = 9: w = J_X E^-1 dP - e, the tenth column of the camera rows
 #pragma unroll
@@ -1397,7 +1429,7 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
             gB[(size_t)k * 32 + 9] = x0.x * d0 + x1.x * d1 + x2.x * d2 - cv.x;
             gB[(size_t)k * 32 + 25] = x0.y * d0 + x1.y * d1 + x2.y * d2 - cv.y;
           } else {
-            const double sg = (j >= 3 && j < 6) ? -1.0 : 1.0;
+            const double sg = (j >= 3 && j < 6) ? -1.0 : 1.0, live = sF[k] * cu;  // (the constant columns 1 / f0 of an observation that exists)
             const double jx = j == 1 ? live : (j == 2 ? 0.0 : sg * cv.x), jy = j == 2 ? live : (j == 1 ? 0.0 : sg * cv.y);
             gB[(size_t)k * 32 + j] = jx;
             gB[(size_t)k * 32 + 16 + j] = jy;
@@ -1410,14 +1442,22 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
       }
     };
     long long ch = blockIdx.x;
+    if (TABLE) fetch_ids(ch);
     fetch(ch);
+    if (TABLE) fetch_ids(ch + gridDim.x);         // (past the last chunk: -1, zero records nobody reads)
     build(0);
-    if (ch + gridDim.x < n_chunks) fetch(ch + gridDim.x);
+    if (ch + gridDim.x < n_chunks) {
+      fetch(ch + gridDim.x);
+      if (TABLE) fetch_ids(ch + 2 * (long long)gridDim.x);
+    }
     __syncthreads();
     for (int b = 0; ch < n_chunks; ch += gridDim.x, b ^= 1) {
       if (ch + gridDim.x < n_chunks) {
         build(b ^ 1);
-        if (ch + 2 * (long long)gridDim.x < n_chunks) fetch(ch + 2 * (long long)gridDim.x);
+        if (ch + 2 * (long long)gridDim.x < n_chunks) {
+          fetch(ch + 2 * (long long)gridDim.x);
+          if (TABLE) fetch_ids(ch + 3 * (long long)gridDim.x);
+        }
       }
       __syncthreads();
     }
@@ -1432,17 +1472,17 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
   __syncthreads();  // chunk 0 is built
   int b = 0;
   for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
-    const double *bG = sG + (size_t)b * 3 * CH * W, *bB = sB + (size_t)b * CH * m * 32;
+    const double *bG = sG + (size_t)b * 3 * CH * W, *bB = sB + (size_t)b * CH * m * 32, *bS = sSgn + (size_t)b * 3 * CH;
 #if !(MVBA_DENSE_KO & 1)
     switch (wave) {  // (uniform)
-      case 0: dense_main_mfma<T, 0, CH>(bG, li, lk, acc); break;
-      case 1: dense_main_mfma<T, 1, CH>(bG, li, lk, acc); break;
-      case 2: dense_main_mfma<T, 2, CH>(bG, li, lk, acc); break;
-      case 3: dense_main_mfma<T, 3, CH>(bG, li, lk, acc); break;
-      case 4: dense_main_mfma<T, 4 % NC, CH>(bG, li, lk, acc); break;  // (cases 4..7 exist with eight consumers only)
-      case 5: dense_main_mfma<T, 5 % NC, CH>(bG, li, lk, acc); break;
-      case 6: dense_main_mfma<T, 6 % NC, CH>(bG, li, lk, acc); break;
-      default: dense_main_mfma<T, 7 % NC, CH>(bG, li, lk, acc); break;
+      case 0: dense_main_mfma<T, 0, CH>(bG, bS, li, lk, acc); break;
+      case 1: dense_main_mfma<T, 1, CH>(bG, bS, li, lk, acc); break;
+      case 2: dense_main_mfma<T, 2, CH>(bG, bS, li, lk, acc); break;
+      case 3: dense_main_mfma<T, 3, CH>(bG, bS, li, lk, acc); break;
+      case 4: dense_main_mfma<T, 4 % NC, CH>(bG, bS, li, lk, acc); break;  // (cases 4..7 exist with eight consumers only)
+      case 5: dense_main_mfma<T, 5 % NC, CH>(bG, bS, li, lk, acc); break;
+      case 6: dense_main_mfma<T, 6 % NC, CH>(bG, bS, li, lk, acc); break;
+      default: dense_main_mfma<T, 7 % NC, CH>(bG, bS, li, lk, acc); break;
     }
 #endif
 #if !(MVBA_DENSE_KO & 8)
@@ -3182,6 +3222,7 @@ struct mvba_handle {
   int4 *d_units = nullptr;
   double *d_partial = nullptr;
   double *d_dense_part = nullptr;     // SCHUR_DENSE: partial tiles per workgroup
+  int *d_dense_obs = nullptr;         // ... and, with missing observations, the observation of every (point, camera) or -1
   int dense_blocks = 0, dense_tiles = 0;
   bool dense_attr_set = false;
   // state: [cur] committed, [1-cur] trial
@@ -3588,16 +3629,31 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     if (v > 0.0 && v < 1.0) h->check_solve_tol = v;
   }
   if (m > 65535) h->schur_mode = SCHUR_STRIP;
-  {  // full visibility with up to 21 cameras (every point's observations are cameras 0 .. m - 1 in order): the dense form, no index
-    bool dense_ok = m >= 1 && 9 * m <= 16 * DENSE_MAX_TILES && nobs == N * (long long)m && N > 0;
-    for (long long a = 0; a < N && dense_ok; ++a) {
-      if (p->pt_ptr[a + 1] - p->pt_ptr[a] != m) { dense_ok = false; break; }
+  std::vector<int> dense_obs;  // SCHUR_DENSE with missing observations: [N][m] observation of (point, camera) or -1
+  {  // up to 21 cameras and most (point, camera) pairs observed: the dense form (no pair index).  Full visibility in camera order
+     // (the reference's own scenes): a point's records are read as one contiguous range; otherwise through a table, a missing
+     // observation standing as a zero record (the matrix cores multiply the zeros: worth it from ~60 % visibility on)
+    bool few = m >= 1 && 9 * m <= 16 * DENSE_MAX_TILES && N > 0, full = few && nobs == N * (long long)m;
+    for (long long a = 0; a < N && full; ++a) {
+      if (p->pt_ptr[a + 1] - p->pt_ptr[a] != m) { full = false; break; }
       const int *ci = p->cam_idx + p->pt_ptr[a];
       for (int k = 0; k < m; ++k)
-        if (ci[k] != k) { dense_ok = false; break; }
+        if (ci[k] != k) { full = false; break; }
     }
     const char *ev = getenv("MVBA_SCHUR");
-    if (dense_ok && (!ev || !strcmp(ev, "dense"))) h->schur_mode = SCHUR_DENSE;
+    const bool forced = ev && !strcmp(ev, "dense");
+    bool masked = few && !full && (forced || (!ev && (double)nobs >= 0.6 * (double)N * m)) && (long long)N * m < (1LL << 31);
+    if (masked) {
+      dense_obs.assign((size_t)N * m, -1);
+      for (long long a = 0; a < N && masked; ++a)
+        for (long long o = p->pt_ptr[a]; o < p->pt_ptr[a + 1]; ++o) {
+          int &slot = dense_obs[(size_t)a * m + p->cam_idx[o]];
+          if (slot >= 0) { masked = false; break; }  // (a camera twice in one point: the pair-major forms take such scenes)
+          slot = (int)o;
+        }
+      if (!masked) dense_obs.clear();
+    }
+    if ((full && (!ev || forced)) || masked) h->schur_mode = SCHUR_DENSE;
   }
   h->use_pairs = h->schur_mode != SCHUR_STRIP && h->schur_mode != SCHUR_DENSE;
   std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units, st_k, st_l, st_a, wunits, seg_end;
@@ -4287,6 +4343,10 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     h->dense_tiles = T * (T + 1) / 2 + m;
     h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + (T <= 8 ? DCH : DCH / 2) - 1) / (T <= 8 ? DCH : DCH / 2), n_cu_dense));  // one workgroup (eight waves, ~110 KB of LDS) per CU
     TRY(dmalloc(&h->d_dense_part, (size_t)h->dense_blocks * h->dense_tiles * 256));
+    if (!dense_obs.empty()) {
+      TRY(dmalloc(&h->d_dense_obs, dense_obs.size()));
+      TRYH(hipMemcpy(h->d_dense_obs, dense_obs.data(), sizeof(int) * dense_obs.size(), hipMemcpyHostToDevice));
+    }
   }
   if (h->use_pairs) {
     const size_t P1 = (size_t)m * (m + 1) / 2 + 1;
@@ -4394,7 +4454,7 @@ void mvba_destroy(mvba_handle *h) {
   void *ptrs[] = {h->d_pt_ptr, h->d_cam, h->d_obs_pt, h->d_xy, h->d_csc, h->d_tiles, h->d_tile_slot, h->d_splits, h->d_PLsplit, h->d_chunk_ptr, h->d_X[0], h->d_X[1],
                   h->d_cam15[0], h->d_cam15[1], h->d_rec, h->d_PL, h->d_PB, h->d_Ab, h->d_Ared, h->d_Ztiles, h->d_Lblk, h->d_lu,
                   h->d_dxi, h->d_dX, h->d_partials, h->d_cost, h->d_flag, h->d_allcost, h->d_it_k, h->d_it_l, h->d_it_a,
-                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_dense_part, h->d_sim, h->d_bar, h->d_wdesc,
+                  h->d_units, h->d_unit_ptr, h->d_q_ptr, h->d_q_units, h->d_q_head, h->d_partial, h->d_dense_part, h->d_dense_obs, h->d_sim, h->d_bar, h->d_wdesc,
                   h->d_wunits, h->d_seg_end, h->d_prog, h->d_trace, h->d_ipiv, h->d_range_o0, h->d_it_x, h->d_cam18, h->d_dxi10};
   for (void *q : ptrs) if (q) hipFree(q);
   for (double *q : h->snap_slabs) hipFree(q);
@@ -4533,31 +4593,25 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
     Timed t(h, MVBA_K_SCHUR);
     const int T = (9 * m + 15) / 16;
     const int CH = T <= 8 ? DCH : DCH / 2;
-    const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8);
+    const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8) + sizeof(double) * (CH * (size_t)m + 2 * 3 * CH);
     auto launch = [&](auto kern) {
       if (!h->dense_attr_set) {  // (once per engine; the limit of the INSTANTIATION -- its largest camera count -- so that engines with other m share it)
         const int mm = 16 * T / 9;
-        const size_t lds_max = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * mm * 32) + sizeof(double2) * CH * ((size_t)mm * REC + 8);
+        const size_t lds_max = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * mm * 32 + (size_t)CH * mm + 2 * 3 * CH) + sizeof(double2) * CH * ((size_t)mm * REC + 8);
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         h->dense_attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (long long)h->N, m,
-                         1.0 / h->f0, h->d_dense_part);
+      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (const int *)h->d_dense_obs,
+                         (long long)h->N, m, 1.0 / h->f0, h->d_dense_part);
     };
+    const bool table = h->d_dense_obs != nullptr;
+#define MVBA_DENSE_CASE(t) case t: if (table) launch(k_schur_dense<t, true>); else launch(k_schur_dense<t, false>); break;
     switch (T) {
-      case 1: launch(k_schur_dense<1>); break;
-      case 2: launch(k_schur_dense<2>); break;
-      case 3: launch(k_schur_dense<3>); break;
-      case 4: launch(k_schur_dense<4>); break;
-      case 5: launch(k_schur_dense<5>); break;
-      case 6: launch(k_schur_dense<6>); break;
-      case 7: launch(k_schur_dense<7>); break;
-      case 8: launch(k_schur_dense<8>); break;
-      case 9: launch(k_schur_dense<9>); break;
-      case 10: launch(k_schur_dense<10>); break;
-      case 11: launch(k_schur_dense<11>); break;
-      default: launch(k_schur_dense<12>); break;
+      MVBA_DENSE_CASE(1) MVBA_DENSE_CASE(2) MVBA_DENSE_CASE(3) MVBA_DENSE_CASE(4) MVBA_DENSE_CASE(5) MVBA_DENSE_CASE(6)
+      MVBA_DENSE_CASE(7) MVBA_DENSE_CASE(8) MVBA_DENSE_CASE(9) MVBA_DENSE_CASE(10) MVBA_DENSE_CASE(11)
+      default: if (table) launch(k_schur_dense<12, true>); else launch(k_schur_dense<12, false>); break;
     }
+#undef MVBA_DENSE_CASE
     const long long n_el = (long long)nA + 9 * m;
     hipLaunchKernelGGL(k_schur_dense_finish, dim3((unsigned)((n_el + 3) / 4)), dim3(256), 0, h->stream, m, T, h->dense_blocks,
                        (const double *)h->d_dense_part, c, d_A, d_b);

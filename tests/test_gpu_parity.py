@@ -576,7 +576,8 @@ def test_barrier_timeout_of_the_persistent_back_substitution_is_redone_with_laun
                                          (3000, 14, 0.5, "slots"), (20000, 60, 0.15, "slots"), (20000, 60, 0.15, "pairs"),
                                          (3000, 14, 0.5, "slots:3"), (20000, 60, 0.15, "slots:4"), (2500, 300, 0.04, "slots"),
                                          (2000, 500, 0.03, "slots"), (3001, 12, 1.0, "dense"), (1003, 21, 1.0, "dense"), (50, 2, 1.0, "dense"),
-                                         (3001, 12, 1.0, "pairs"), (999, 21, 1.0, "slots")])
+                                         (3001, 12, 1.0, "pairs"), (999, 21, 1.0, "slots"), (3001, 14, 0.8, "dense"), (2003, 21, 0.65, "dense"),
+                                         (1000, 6, 0.5, "dense")])
 def test_every_schur_kernel_form_matches_the_oracle(n, m, p, form, monkeypatch):
     """The three forms of K3 -- the camera-strip kernel (round 1, plain and column-segmented), the
     pair-major unit kernel (round 2) and the slot-resident kernel (round 3: one round of all camera pairs up to
@@ -585,7 +586,8 @@ def test_every_schur_kernel_form_matches_the_oracle(n, m, p, form, monkeypatch):
     MVBA_SCHUR, the first two in their 64-bit-offset build (MVBA_FORCE_BIG; the slot form addresses its records
     relative to the point range instead), and the dense-visibility form (round 5: every point seen by every camera, up to 21
     cameras -- the rank-3N update of the whole reduced matrix on the matrix cores, no index; point counts that are not a multiple
-    of its chunk, the largest and the smallest camera count, and the pair-major forms on the same full-visibility scenes),
+    of its chunk, the largest and the smallest camera count, the pair-major forms on the same full-visibility scenes, and scenes
+    with MISSING observations -- the records then come through a (point, camera) table and a missing one is a zero record),
     against the oracle's reduced system."""
     if ":" in form:
         form, groups = form.split(":")
@@ -971,3 +973,32 @@ def test_dense_form_engines_with_different_camera_counts_alive_together():
         engines.append(ba._engine)
     costs = [[e.try_step(1e-3) for e in engines] for _ in range(3)]
     assert np.all(np.isfinite(costs)) and costs[0] == costs[1] == costs[2]
+
+
+def test_dense_form_is_chosen_by_visibility():
+    """mvba_create's choice: up to 21 cameras and at least 60 % of the (point, camera) pairs observed -> the dense form (through the
+    observation table unless every point lists all cameras); sparser or larger scenes stay on the pair-major forms.  A scene in which
+    ONE observation is missing goes through the table and gives, on the other points' side, what the full scene's contiguous path
+    gives: the two paths share everything but the way the records are fetched."""
+    def engine(n, m, p, drop=None):
+        sc = make_scene(n, m, vis_p=p)
+        keep = np.ones(sc.n_obs, bool)
+        if drop is not None:
+            keep[drop] = False
+        counts = np.diff(sc.pt_ptr)
+        pt_of = np.repeat(np.arange(n), counts)
+        pt_ptr = np.concatenate([[0], np.cumsum(np.bincount(pt_of[keep], minlength=n))])
+        ba = BundleAdjuster.from_observations(sc.n_points, m, pt_ptr, sc.cam_idx[keep], sc.xy[keep], sc.init_X, sc.init_K, sc.init_R, sc.init_t, axis=sc.axis)
+        return ba._engine
+
+    assert engine(800, 10, 1.0).schur_info()["kernel"] == "dense" and engine(800, 10, 0.8).schur_info()["kernel"] == "dense"
+    assert engine(800, 10, 0.4).schur_info()["kernel"] != "dense" and engine(800, 25, 1.0).schur_info()["kernel"] != "dense"
+    full, holed = engine(700, 9, 1.0), engine(700, 9, 1.0, drop=699 * 9 + 4)  # the last point loses its fifth camera
+    out = []
+    for eng in (full, holed):
+        assert eng.schur_info()["kernel"] == "dense"
+        eng.linearize()
+        eng.try_step(1e-3)
+        out.append(eng.debug_read("A_full").reshape(81, 81).copy())
+    # one observation of 6300 less: the camera blocks barely move, and not at all in a way a wrong fetch would explain
+    assert np.abs(out[1] - out[0]).max() < 5e-3 * np.abs(out[0]).max() and np.abs(out[1] - out[0]).max() > 0.0
