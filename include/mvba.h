@@ -125,8 +125,8 @@ int mvba_reset_stats(mvba_handle *h);
 /* Sizes of the Schur index built at create and what the communicator runs on (bench.py prices the
  * kernels with them): out[0] (point, camera pair) items incl. diagonal pairs, out[1] off-diagonal
  * items, out[2] units (wave runs / slot lists), out[3] Schur kernel form: 0 = camera strips (round 1),
- * 1 = pair-major units (round 2), 2 = slot-resident (round 3), 3 = dense visibility (round 5: every point seen by every camera,
- * at most 21 cameras: no index, out[0..2] = 0) in bits 0..7, the slot form's rounds (camera-group pairs swept one
+ * 1 = pair-major units (round 2), 2 = slot-resident (round 3), 3 = dense visibility (round 5: at most 21 cameras and at least
+ * 60 % of the (point, camera) pairs observed: no pair index, out[0..2] = 0) in bits 0..7, the slot form's rounds (camera-group pairs swept one
  * after the other inside the launch) in bits 8..31 and camera groups in bits 32.., out[4] ncclGetVersion() of the librccl
  * actually loaded (0 without a communicator), out[5] the NCCL_VERSION_CODE the library was compiled
  * against, out[6] ranks, out[7] slot form: step-major item rows including the padding rows. */
