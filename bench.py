@@ -276,12 +276,18 @@ def dense_visibility_leg(device, steps=10, n_pts=1_000_000, n_cams=12):
         eng.reset_stats()
         s0 = eng.n_solves
         torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()  # (as in the main timed region: with torch imported a full collection is a 50 ms step now and then)
+        step_s = []
         t0 = time.perf_counter()
         for _ in range(steps):
+            ts = time.perf_counter()
             E_ = lm.iterate()[0]
             lm.carry_on(E_)
+            step_s.append(time.perf_counter() - ts)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         st = eng.stats()
         solves = eng.n_solves - s0
         info = eng.schur_info()
@@ -290,6 +296,7 @@ def dense_visibility_leg(device, steps=10, n_pts=1_000_000, n_cams=12):
         k3_ms = st["schur"]["ms"] / max(st["schur"]["launches"], 1)
         return {"workload": f"{n_pts} points x {n_cams} cameras, full visibility = {sc.n_obs} observations, D = {9 * n_cams - 7}; {steps} LM iterations after one warm-up",
                 "steps": steps, "inner_solves": solves, "ms_per_step": dt / steps * 1e3, "it_per_s": steps / dt,
+                "step_ms": {"min": min(step_s) * 1e3, "median": float(np.median(step_s)) * 1e3, "max": max(step_s) * 1e3},
                 "kernel_ms_per_solve": {k: v["ms"] / max(solves, 1) for k, v in st.items() if k != "counts"},
                 "rmse_start": float(np.sqrt(E0 / sc.n_obs)), "rmse_end": float(np.sqrt(E_ / sc.n_obs)), "engine_create_s": t_create,
                 "roofline": schur_roofline(info, sc.n_obs, k3_ms, n_cu)}
