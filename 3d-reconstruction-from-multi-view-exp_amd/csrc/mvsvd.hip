@@ -2869,8 +2869,10 @@ int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows) {
 
 int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
                      double *timings_ms) {
-  if (!h || !z || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
+  if (!h || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
   if (!h->base_loaded) return fail(MVBA_ERR_STATE, "mvsvd_run_scaled before mvsvd_load_base");
+  // z == NULL: the depths a device depth loop left in the workspace (same grouping) -- nothing is uploaded at all
+  if (!z && (h->depth_group != group || !h->dz)) return fail(MVBA_ERR_STATE, "mvsvd_run_scaled without depths: no device depth loop of this grouping has run");
   if (group < 1 || h->n % group) return fail(MVBA_ERR_BADARG, "group must divide n_cols");
   if (norm < 0 || norm > 2) return fail(MVBA_ERR_BADARG, "norm must be 0 (none), 1 (unit rows) or 2 (column groups by their squared norm)");
   if (n_rank < 1 || n_rank > h->n) return fail(MVBA_ERR_BADARG, "need 1 <= n_rank <= n_cols");
@@ -2879,7 +2881,7 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   const size_t el = h->dtype ? 8 : 4;
   if (!h->dz) MVBA_HIP(hipMalloc(&h->dz, el * (size_t)h->max_rows * h->n));  // (room for any grouping: a later call may ask for a finer one)
   hipEventRecord(h->ev[0], h->st);
-  MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
+  if (z) MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
   hipEventRecord(h->ev[1], h->st);
   h->depth_group = 0;  // (the caller's depths replace whatever a depth loop held)
   int rc = scale_base_into_w(h, group, norm);

@@ -352,16 +352,17 @@ class SvdWorkspace:
     def run_scaled(self, z, group, norm, n_rank):
         """Factorise X o z (depths z (n_rows, n_cols / group) per column group, normalised: norm 1 = unit rows,
         2 = column groups by their squared norm) from the resident base: only z is uploaded.
-        M (n_cols, r), sigma (n_cols,), S (r, n_rows), timings."""
-        z = np.ascontiguousarray(z, dtype=self.dtype)
-        if z.shape != (self.base_rows, self.n_cols // int(group)):
-            raise ValueError("z must be (rows of the base, n_cols / group)")
+        M (n_cols, r), sigma (n_cols,), S (r, n_rows), timings.  z = None: the depths a device depth loop left in the workspace."""
+        if z is not None:
+            z = np.ascontiguousarray(z, dtype=self.dtype)
+            if z.shape != (self.base_rows, self.n_cols // int(group)):
+                raise ValueError("z must be (rows of the base, n_cols / group)")
         self.n_rows = self.base_rows  # the workspace matrix becomes the re-weighted base
         M = np.empty((self.n_cols, n_rank), self.dtype)
         sigma = np.empty(self.n_cols, self.dtype)
         S = np.empty((n_rank, self.n_rows), self.dtype)
         tm = np.zeros(6)
-        raise_for(self.lib.mvsvd_run_scaled(self._h, z.ctypes.data, int(group), int(norm), int(n_rank), M.ctypes.data,
+        raise_for(self.lib.mvsvd_run_scaled(self._h, z.ctypes.data if z is not None else None, int(group), int(norm), int(n_rank), M.ctypes.data,
                                             sigma.ctypes.data, S.ctypes.data, _ptr(tm)), self.lib)
         return M, sigma, S, _tm(tm)
 

@@ -224,7 +224,8 @@ int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *si
  * the group's (X o z)^2 over all rows (norm 2: every column group -- image -- divided by its squared Frobenius
  * norm, ref :170-172) or s = 1 (norm 0).  mvsvd_load_base uploads X (n_rows x n_cols, the workspace's dtype) once;
  * every mvsvd_run_scaled uploads only z (n_rows x n_cols / group), forms W on the device and runs the factorisation
- * (no centring).  timings_ms[0] is then the upload of z. */
+ * (no centring).  timings_ms[0] is then the upload of z.  z == NULL: the depths a device depth loop (below) left in the workspace,
+ * same grouping -- nothing is uploaded: the final factorisation of perspective_self_calibration (ref :531-533) without W on the host. */
 int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows);
 int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
                      double *timings_ms);

@@ -45,11 +45,12 @@ def run(n_points=1_000_000, n_images=12, max_iter=30, tol=1e-2, noise=1e-3, quie
     stages["scene generation (not part of the pipeline)"] = time.perf_counter() - t0
 
     saved = [(PC, n, timed(PC, n, lab)) for n, lab in (("_create_data_matrix", "self-calibration: _create_data_matrix"),
-                                                        ("_compute_projective_depth_dual_method", "self-calibration: projective depths (device loop, incl. upload)"),
-                                                        ("factorization_method", "self-calibration: factorization_method (upload + device SVD)"),
+                                                        ("_depth_iterations", "self-calibration: projective depths (device loop)"),
                                                         ("_euclidean_upgrading", "self-calibration: _euclidean_upgrading"),
                                                         ("_reconstruct_3d", "self-calibration: _reconstruct_3d"),
                                                         ("correct_world_coordinates", "self-calibration: correct_world_coordinates"))]
+    saved += [(PC._DeviceDepthLoop, "__init__", timed(PC._DeviceDepthLoop, "__init__", "self-calibration: upload of the observations (depth loop workspace)")),
+              (PC._DeviceDepthLoop, "factorize", timed(PC._DeviceDepthLoop, "factorize", "self-calibration: final factorisation of x o z (on the device, no upload)"))]
     saved += [(BA, "dense_to_observations", timed(BA, "dense_to_observations", "BundleAdjuster(): dense_to_observations")),
               (BA, "to_gauge_frame", timed(BA, "to_gauge_frame", "BundleAdjuster(): to_gauge_frame")),
               (BA, "lm_loop", timed(BA, "lm_loop", "optimize(): LM loop on the device"))]
