@@ -3430,6 +3430,14 @@ int launch_cost(mvba_handle *h, const double *cam15, const double *X) {
   return MVBA_OK;
 }
 
+// mvba_create, xy_layout 1: the observations of a fully visible scene arrive as image planes [m][N] and leave in observation
+// order [N][m] (a wave reads 1 KiB of one plane and writes 64 records m * 16 bytes apart; once per engine)
+__global__ __launch_bounds__(256) void k_xy_from_planes(const double2 *__restrict__ planes, long long N, int m, double2 *__restrict__ xy) {
+  const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (a < N) xy[a * m + k] = planes[(long long)k * N + a];
+}
+
 }  // namespace
 
 extern "C" {
@@ -3457,9 +3465,28 @@ int mvba_device_count(int32_t *count) {
 
 int mvba_create(const mvba_problem *p, mvba_handle **out) {
   if (!p || !out) return fail(MVBA_ERR_BADARG, "null argument");
+  // MVBA_CREATE_TRACE=1: wall time of this function's stages to stderr (tools/time_pipeline.py: the engine's construction is a
+  // third of the reference's pipeline at 1 M points x 12 images)
+  struct Trace {
+    bool on = getenv("MVBA_CREATE_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::string s;
+    void mark(const char *label) {
+      if (!on) return;
+      const auto n = std::chrono::steady_clock::now();
+      char buf[96];
+      snprintf(buf, sizeof buf, " %s %.1f ms;", label, std::chrono::duration<double, std::milli>(n - t).count());
+      s += buf;
+      t = n;
+    }
+    ~Trace() { if (on) fprintf(stderr, "mvba_create:%s\n", s.c_str()); }
+  } trace;
   if (p->n_points < 0 || p->n_images < 2 || p->n_obs < 0 || !p->pt_ptr || (p->n_obs && (!p->cam_idx || !p->xy)))
     return fail(MVBA_ERR_BADARG, "bad problem sizes or null arrays (need n_images >= 2)");
   if (p->gauge_axis != 0 && p->gauge_axis != 1) return fail(MVBA_ERR_BADARG, "gauge_axis must be 0 or 1");
+  if (p->xy_layout != 0 && p->xy_layout != 1) return fail(MVBA_ERR_BADARG, "xy_layout must be 0 (observation order) or 1 (image planes)");
+  if (p->xy_layout == 1 && p->n_obs != p->n_points * (int64_t)p->n_images)
+    return fail(MVBA_ERR_BADARG, "xy as image planes needs every point observed in every image (n_obs = n_points * n_images)");
   // the kernels keep the whole camera table in LDS (K1: 18 doubles per camera + 8 x 8 KiB of wave
   // tiles; back-substitution: 28 per camera): 160 KiB per workgroup caps the camera count.  (The documented limit is
   // round 1's, from 19 doubles per camera; 18 would admit 682.)
@@ -3499,6 +3526,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
       csc_ptr[k + 1]++;
     }
   }
+  trace.mark("validation pass");
   for (int k = 0; k < m; ++k) csc_ptr[k + 1] += csc_ptr[k];
   // the camera-major index belongs to the strip kernel alone (round 1's K3: MVBA_SCHUR=strip, or more cameras than a
   // pair id holds): 160 MB at config 3 that the other forms never read
@@ -3554,6 +3582,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   }
   h->N = N; h->nobs = nobs; h->m = m; h->gauge_axis = p->gauge_axis; h->f0 = p->f0; h->D = 9 * m - 7; h->ld = (h->D + 3) & ~3;
   h->gcam = m > LDS_CAMERAS;
+  trace.mark("K1 tiles, device");
 #define TRY(x) do { int rc_ = (x); if (rc_) { mvba_destroy(h); return rc_; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mvba_destroy(h); return fail(MVBA_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
   // the topology goes up first: the Schur index is built from it on the device
@@ -3563,6 +3592,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   TRYH(hipMemcpy(h->d_pt_ptr, p->pt_ptr, sizeof(long long) * (N + 1), hipMemcpyHostToDevice));
   if (nobs) TRYH(hipMemcpy(h->d_cam, p->cam_idx, sizeof(int) * nobs, hipMemcpyHostToDevice));
 
+  trace.mark("topology upload");
   // Schur launch geometry (measured sweep at config 3, profiles/): ~800 camera-list entries per
   // block is the optimum (tail balance vs strip flush); small problems still get >= 2048 blocks
   // as long as a block keeps >= 128 entries.
@@ -3655,6 +3685,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     }
     if ((full && (!ev || forced)) || masked) h->schur_mode = SCHUR_DENSE;
   }
+  trace.mark("form of K3");
   h->use_pairs = h->schur_mode != SCHUR_STRIP && h->schur_mode != SCHUR_DENSE;
   std::vector<int> it_k, it_l, it_a, unit_ptr, q_ptr(9, 0), q_units, st_k, st_l, st_a, wunits, seg_end;
   std::vector<int4> units, wdesc;
@@ -4289,6 +4320,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   h->cost_grid = (int)std::max<long long>(1, std::min<long long>(2048, (nobs + 255) / 256));
   h->n_partials = std::max(h->cost_grid, 4096);  // k_cost uses cost_grid blocks
 
+  trace.mark("K3 index");
   TRY(dmalloc(&h->d_obs_pt, nobs));
   TRY(dmalloc(&h->d_xy, nobs));
   TRY(dmalloc(&h->d_csc, csc.size()));
@@ -4326,9 +4358,23 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
   memset(h->h_cost, 0, 4 * sizeof(double));
   if (hipHostGetDevicePointer((void **)&h->d_mail, h->h_cost, 0) != hipSuccess) h->d_mail = nullptr;  // (no mapping: copy + sync as before)
   h->h_flag = reinterpret_cast<int *>(h->h_cost + 1);  // cost and flags come back in one copy
+  trace.mark("allocations");
   if (nobs) {
     TRYH(hipMemcpy(h->d_obs_pt, obs_pt.data(), sizeof(int) * nobs, hipMemcpyHostToDevice));
-    TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
+    if (p->xy_layout == 1) {  // image planes [m][N][2], as a caller's stack of per-image arrays lies in memory: into observation order here
+      double2 *planes = nullptr;  // (the host's strided gather of the same bytes: 0.1 s at 1 M points x 12 images)
+      TRYH(hipMalloc((void **)&planes, sizeof(double2) * nobs));
+      hipError_t e = hipMemcpy(planes, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xy_from_planes, dim3((unsigned)((N + 255) / 256), m), dim3(256), 0, 0, planes, N, m, h->d_xy);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+      }
+      hipFree(planes);
+      TRYH(e);
+    } else {
+      TRYH(hipMemcpy(h->d_xy, p->xy, sizeof(double2) * nobs, hipMemcpyHostToDevice));
+    }
     if (want_strip) TRYH(hipMemcpy(h->d_csc, csc.data(), sizeof(int4) * nobs, hipMemcpyHostToDevice));
   }
   TRYH(hipMemcpy(h->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
@@ -4396,6 +4442,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     TRYH(hipMemset(h->d_q_head, 0, sizeof(int) * 64));
     TRYH(hipMemset(h->d_partial, 0, sizeof(double) * UNIT_STRIDE * std::max<size_t>(units.size(), 1)));
   }
+  trace.mark("uploads");
   // opt in to large dynamic LDS
   const int strip_lds = (int)((81 * (size_t)h->lseg + 9) * sizeof(double));
   TRYH(hipFuncSetAttribute((const void *)k_schur_strip<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds));
@@ -4427,6 +4474,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
 #undef TRY
 #undef TRYH
   lap("device allocations + uploads");
+  trace.mark("attributes");
   *out = h;
   return MVBA_OK;
 }

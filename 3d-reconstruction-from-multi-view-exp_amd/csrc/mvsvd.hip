@@ -1144,6 +1144,19 @@ __global__ void k_group_scale(const double *__restrict__ part, int blocks, int n
   if (lane == 0) cs[g] = 1.0 / t;
 }
 
+// mvsvd_load_base_images: one image's pixel coordinates [n_rows][2] (doubles, as the caller holds them) into its three columns
+// of the base, homogeneous: (x / f0, y / f0, 1)   (ref lib/perspective_camera_calibration.py:34-40)
+template <typename T>
+__global__ __launch_bounds__(256) void k_base_image(const double2 *__restrict__ xy, long long n_rows, int n, int col, double f0, T *__restrict__ X) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  const double2 p = xy[i];
+  T *o = X + i * n + col;
+  o[0] = (T)(p.x / f0);
+  o[1] = (T)(p.y / f0);
+  o[2] = (T)1;
+}
+
 // Rows too long for the LDS tiles (more than ~57 fp64 / 117 fp32 columns + depths): the lanes of a wave run ACROSS the column
 // groups of a row -- P = ng rounded up to a power of two lanes per row, 64 / P rows per pass (beyond 64 groups: one row, the lanes
 // striding over its groups) -- so that a pass reads and writes one contiguous range; the row's sum of squares (norm 1) is a
@@ -2867,6 +2880,35 @@ int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows) {
   return MVBA_OK;
 }
 
+int mvsvd_load_base_images(mvsvd_handle *h, const double *const *xy, int32_t n_images, int64_t n_rows, double f0) {
+  if (!h || !xy) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_rows < 1 || n_rows > h->max_rows) return fail(MVBA_ERR_BADARG, "n_rows outside the workspace (1 .. max_rows)");
+  if (n_images < 1 || 3 * (long long)n_images != h->n) return fail(MVBA_ERR_BADARG, "the workspace must have 3 columns per image");
+  if (!(f0 != 0.0) || !std::isfinite(f0)) return fail(MVBA_ERR_BADARG, "f0 must be finite and non-zero");
+  for (int k = 0; k < n_images; ++k)
+    if (!xy[k]) return fail(MVBA_ERR_BADARG, "null image array");
+  MVBA_HIP(hipSetDevice(h->device));
+  const size_t el = h->dtype ? 8 : 4;
+  if (!h->dX) MVBA_HIP(hipMalloc(&h->dX, el * (size_t)h->max_rows * h->n));
+  // staged through dW (16 bytes a row <= el * n: there are at least 6 columns), image after image in stream order
+  if (el * (size_t)h->n < 16) return fail(MVBA_ERR_BADARG, "the workspace is too narrow to stage an image");
+  const unsigned grid = (unsigned)((n_rows + 255) / 256);
+  for (int k = 0; k < n_images; ++k) {
+    MVBA_HIP(hipMemcpyAsync(h->dW, xy[k], 16 * (size_t)n_rows, hipMemcpyHostToDevice, h->st));
+    if (h->dtype)
+      hipLaunchKernelGGL(k_base_image<double>, dim3(grid), dim3(256), 0, h->st, (const double2 *)h->dW, (long long)n_rows, h->n, 3 * k, f0, (double *)h->dX);
+    else
+      hipLaunchKernelGGL(k_base_image<float>, dim3(grid), dim3(256), 0, h->st, (const double2 *)h->dW, (long long)n_rows, h->n, 3 * k, f0, (float *)h->dX);
+  }
+  MVBA_HIP(hipGetLastError());
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  h->base_rows = n_rows;
+  h->base_loaded = true;
+  h->wide_warm = h->wide_have_q = false;
+  h->loaded = false;  // dW was the staging buffer
+  return MVBA_OK;
+}
+
 int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
                      double *timings_ms) {
   if (!h || !M || !sigma || !S) return fail(MVBA_ERR_BADARG, "null argument");
@@ -2883,7 +2925,7 @@ int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm
   hipEventRecord(h->ev[0], h->st);
   if (z) MVBA_HIP(hipMemcpyAsync(h->dz, z, el * (size_t)h->base_rows * ng, hipMemcpyHostToDevice, h->st));  // the only upload of the call
   hipEventRecord(h->ev[1], h->st);
-  h->depth_group = 0;  // (the caller's depths replace whatever a depth loop held)
+  if (z) h->depth_group = 0;  // (the caller's depths replace whatever a depth loop held)
   int rc = scale_base_into_w(h, group, norm);
   if (rc) return rc;
   MVBA_HIP(hipStreamSynchronize(h->st));

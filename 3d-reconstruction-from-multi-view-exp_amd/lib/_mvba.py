@@ -28,7 +28,7 @@ class Problem(C.Structure):
     _fields_ = [("n_points", C.c_int64), ("n_obs", C.c_int64), ("n_images", C.c_int32),
                 ("gauge_axis", C.c_int32), ("pt_ptr", C.POINTER(C.c_int64)),
                 ("cam_idx", C.POINTER(C.c_int32)), ("xy", _dp), ("f0", C.c_double),
-                ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("xy_layout", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "mvsvd_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mvsvd_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
     "mvsvd_load_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mvsvd_load_base_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_double]),
     "mvsvd_run_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
     "mvsvd_depth_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "mvsvd_depth_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp, _dp]),
@@ -141,11 +142,16 @@ class HipEngine:
         self.n, self.m = int(n_points), int(n_images)
         self._pt_ptr = _as(pt_ptr, np.int64)
         self._cam = _as(cam_idx, np.int32)
-        self._xy = _as(xy, np.float64).reshape(-1, 2)
+        self._xy = _as(xy, np.float64)
+        planes = self._xy.ndim == 3  # (m, N, 2) image planes of a fully visible scene (xy_layout 1) instead of (n_obs, 2)
+        if planes and self._xy.shape != (self.m, self.n, 2):
+            raise ValueError("xy as image planes must be (n_images, n_points, 2)")
+        if not planes:
+            self._xy = self._xy.reshape(-1, 2)
         self.n_obs = int(self._cam.shape[0])
         prob = Problem(self.n, self.n_obs, self.m, AXES[axis],
                        self._pt_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
-                       self._cam.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(self._xy), float(f0), int(device), 0)
+                       self._cam.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(self._xy), float(f0), int(device), int(planes))
         h = C.c_void_p()
         raise_for(self.lib.mvba_create(C.byref(prob), C.byref(h)), self.lib)
         self._h = h
@@ -347,6 +353,17 @@ class SvdWorkspace:
             raise ValueError("X must be (n_rows, n_cols) of the workspace")
         raise_for(self.lib.mvsvd_load_base(self._h, X.ctypes.data, X.shape[0]), self.lib)
         self.base_rows = X.shape[0]
+        return self
+
+    def load_base_images(self, x_list, f0):
+        """The base (x / f0, y / f0, 1) per image, assembled on the device from the images' (n_rows, 2) arrays themselves."""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in x_list]
+        n_rows = arrs[0].shape[0]
+        if 3 * len(arrs) != self.n_cols or any(a.shape != (n_rows, 2) for a in arrs):
+            raise ValueError("x_list must hold n_cols / 3 arrays of shape (n_rows, 2)")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        raise_for(self.lib.mvsvd_load_base_images(self._h, ptrs, len(arrs), n_rows, float(f0)), self.lib)
+        self.base_rows = n_rows
         return self
 
     def run_scaled(self, z, group, norm, n_rank):

@@ -42,6 +42,22 @@ class _DeviceDepthLoop:
         self._ws.load_base(np.ascontiguousarray(x.reshape(n, 3 * m), dtype=np.float64))
         self._ws.depth_begin(3)
 
+    @classmethod
+    def from_images(cls, x_list: list[npt.NDArray], f0: float):
+        """The same loop from the images' own (N, 2) arrays: x = (x / f0, y / f0, 1) is assembled on the device
+        (`mvsvd_load_base_images`) -- no (N, m, 3) array on the host, two thirds of the bytes over PCIe."""
+        from ._mvba import SvdWorkspace
+
+        self = cls.__new__(cls)
+        self._ws = SvdWorkspace(len(x_list[0]), 3 * len(x_list), np.float64)
+        try:
+            self._ws.load_base_images(x_list, f0)
+            self._ws.depth_begin(3)
+        except Exception:
+            self.close()
+            raise
+        return self
+
     def step(self, method: int, f0: float) -> float:
         return self._ws.depth_step(method, f0)[0]
 
@@ -223,12 +239,14 @@ def correct_world_coordinates(X, R, t, method: str = "first_camera"):
 
 def perspective_self_calibration(x_list: list[npt.NDArray], f0=1.0, tol=0.01, method: str = "primary"):
     """-> (X (N,3), R (m,3,3), t (m,3), K (m,3,3))   (:513-540)"""
-    x = _create_data_matrix(x_list, f0)
     if method not in ("primary", "dual"):
         raise ValueError()
-    # the reference forms W = x * z on the host and factorises it (:531-533); the depths are still on the device here, next to the
-    # observations: the same W is formed and factorised there (0.13 s of host multiply and upload at 1 M points x 12 images)
-    loop = _DeviceDepthLoop(x)
+    # the reference forms x (N, m, 3) and W = x * z on the host and factorises W (:34-40, :531-533); here the images' arrays go to
+    # the device as they are, x is assembled there, and the depths are still there, next to x, when W is formed and factorised
+    # (0.11 s of strided host writes + 0.13 s of host multiply and upload at 1 M points x 12 images)
+    from_images = getattr(_DeviceDepthLoop, "from_images", None)
+    x = None if from_images else _create_data_matrix(x_list, f0)  # (a loop class without the device workspace: the tests' oracle loop)
+    loop = from_images(x_list, f0) if from_images else _DeviceDepthLoop(x)
     try:
         _depth_iterations(x, f0, tol, 200 if method == "primary" else 50, 1 if method == "primary" else 2, loop, close=False)
         if hasattr(loop, "factorize"):

@@ -45,10 +45,13 @@ typedef struct mvba_problem {
   int32_t gauge_axis;     /* 0: "x-right_z-forward" (drops param 12), 1: "x-up_z-forward" (drops 13); ref :62-72 */
   const int64_t *pt_ptr;  /* [n_points+1] offsets into cam_idx / xy              */
   const int32_t *cam_idx; /* [n_obs] camera of each observation, ascending within a point */
-  const double *xy;       /* [n_obs][2] observed image coordinates               */
+  const double *xy;       /* [n_obs][2] observed image coordinates (xy_layout 0) */
   double f0;              /* ref :50                                             */
   int32_t device;         /* HIP device ordinal, -1 = current device             */
-  int32_t reserved;
+  int32_t xy_layout;      /* 0: xy in observation order.  1: xy as image planes [n_images][n_points][2] -- the memory of the
+                           * reference caller's np.stack(x_list) (euclidiean_reconstruction.py:50) -- legal only when every point
+                           * is observed in every image (n_obs = n_points * n_images; pt_ptr / cam_idx as always); the
+                           * observation order is formed on the device instead of by a strided host copy               */
 } mvba_problem;
 
 /* Kernel ids for mvba_stats (names via mvba_kernel_name). */
@@ -227,6 +230,11 @@ int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *si
  * (no centring).  timings_ms[0] is then the upload of z.  z == NULL: the depths a device depth loop (below) left in the workspace,
  * same grouping -- nothing is uploaded: the final factorisation of perspective_self_calibration (ref :531-533) without W on the host. */
 int mvsvd_load_base(mvsvd_handle *h, const void *X, int64_t n_rows);
+/* The same base assembled on the device from the images' own arrays (ref lib/perspective_camera_calibration.py:34-40,
+ * _create_data_matrix: 0.11 s of strided host writes at 1 M points x 12 images, and a third more bytes over PCIe):
+ * xy[k] = image k's pixel coordinates [n_rows][2] (doubles), base[i][3k .. 3k+2] = (x / f0, y / f0, 1) in the workspace's
+ * dtype; n_cols of the workspace must be 3 n_images. */
+int mvsvd_load_base_images(mvsvd_handle *h, const double *const *xy, int32_t n_images, int64_t n_rows, double f0);
 int mvsvd_run_scaled(mvsvd_handle *h, const void *z, int32_t group, int32_t norm, int32_t n_rank, void *M, void *sigma, void *S,
                      double *timings_ms);
 

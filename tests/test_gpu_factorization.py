@@ -565,6 +565,38 @@ def test_depth_iteration_in_float32():
     ws.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_base_assembled_on_the_device_equals_the_host_data_matrix(dtype):
+    """`mvsvd_load_base_images` (the images' (N, 2) arrays as they are; x / f0, y / f0, 1 formed on the device) against
+    `mvsvd_load_base` of `_create_data_matrix`'s array (ref :34-40): the same base bit for bit -- an IEEE division either way --
+    so the factors and a depth iteration that follow are bitwise the same.  Ragged and mis-sized inputs raise."""
+    from lib.perspective_camera_calibration import _create_data_matrix
+
+    rng = np.random.default_rng(31)
+    n, m, f0 = 5003, 7, 612.5
+    x_list = [rng.uniform(-400, 400, (n, 2)) for _ in range(m)]
+    x_list[2] = np.asfortranarray(x_list[2])  # (a non-contiguous image: the binding makes it contiguous)
+    x = _create_data_matrix(x_list, f0).reshape(n, 3 * m).astype(dtype)
+    z = rng.uniform(0.5, 2.0, (n, m)).astype(dtype)
+    a, b = _mvba.SvdWorkspace(n, 3 * m, dtype), _mvba.SvdWorkspace(n, 3 * m, dtype)
+    a.load_base(x)
+    b.load_base_images(x_list, f0)
+    ra, rb = a.run_scaled(z, 3, 2, 4), b.run_scaled(z, 3, 2, 4)
+    for u, v in zip(ra[:3], rb[:3]):
+        assert np.array_equal(u, v, equal_nan=True)
+    a.depth_begin(3), b.depth_begin(3)
+    for method in (1, 2):
+        assert a.depth_step(method, f0)[0] == b.depth_step(method, f0)[0]
+    assert np.array_equal(a.depth_read(), b.depth_read())
+    with pytest.raises(ValueError):
+        b.load_base_images(x_list[:-1], f0)  # 3 columns per image
+    with pytest.raises(ValueError):
+        b.load_base_images(x_list[:-1] + [x_list[0][:-1]], f0)  # ragged
+    with pytest.raises(ValueError):
+        b.load_base_images(x_list, 0.0)
+    a.close(), b.close()
+
+
 @pytest.mark.parametrize("method", [1, 2])
 def test_depth_iteration_at_a_million_points_properties(method):
     """The device depth loop at 1,000,000 points x 8 images (fp64) -- too large for the oracle's per-point eigh in a test, so

@@ -975,6 +975,31 @@ def test_dense_form_engines_with_different_camera_counts_alive_together():
     assert np.all(np.isfinite(costs)) and costs[0] == costs[1] == costs[2]
 
 
+def test_observations_as_image_planes_give_the_same_engine():
+    """`mvba_problem.xy_layout = 1`: the observations of a fully visible scene handed over as the m image planes (m, N, 2) -- the
+    memory of the reference caller's np.stack(x_list) -- and put into observation order on the device, against the list form:
+    cost, reduced system and a trial step are bitwise the same.  Planes of a scene with missing observations, or of another shape, raise."""
+    sc = make_scene(3001, 7, vis_p=1.0)
+    n, m = sc.n_points, 7
+    planes = np.ascontiguousarray(sc.xy.reshape(n, m, 2).transpose(1, 0, 2))
+    a = _mvba.HipEngine(n, m, sc.pt_ptr, sc.cam_idx, sc.xy, 1.0, sc.axis)
+    b = _mvba.HipEngine(n, m, sc.pt_ptr, sc.cam_idx, planes, 1.0, sc.axis)
+    X, R, t = O.normalize_scene(sc.init_X, sc.init_R, sc.init_t, sc.axis)
+    for e in (a, b):
+        e.set_params(X, sc.init_K[:, 0, 0], sc.init_K[:, :2, 2], t, R)
+    assert a.cost() == b.cost()
+    a.linearize(), b.linearize()
+    assert a.try_step(1e-4) == b.try_step(1e-4)
+    for name in ("residual", "A_full", "b_full", "dX"):
+        assert np.array_equal(a.debug_read(name), b.debug_read(name))
+    a.close(), b.close()
+    with pytest.raises(ValueError):
+        _mvba.HipEngine(n, m, sc.pt_ptr, sc.cam_idx, planes[:, :-1], 1.0, sc.axis)
+    part = make_scene(500, 7, vis_p=0.7)
+    with pytest.raises(ValueError):
+        _mvba.HipEngine(500, 7, part.pt_ptr, part.cam_idx, np.zeros((7, 500, 2)), 1.0, part.axis)
+
+
 def test_dense_form_is_chosen_by_visibility():
     """mvba_create's choice: up to 21 cameras and at least 60 % of the (point, camera) pairs observed -> the dense form (through the
     observation table unless every point lists all cameras); sparser or larger scenes stay on the pair-major forms.  A scene in which

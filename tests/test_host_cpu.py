@@ -59,6 +59,8 @@ class _OracleBackedAdjuster(BundleAdjuster):
     """Product host logic (normalisation, LM loop, log, K assembly) over the CPU oracle engine."""
 
     def _make_engine(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, **kw):
+        xy = np.asarray(xy)  # (image planes (m, N, 2) when the caller's x was a transposed stack: the oracle takes the list form)
+        xy = xy.transpose(1, 0, 2).reshape(-1, 2) if xy.ndim == 3 else xy
         return HostOracleEngine(n_points, n_images, pt_ptr, cam_idx, xy, f0, axis)
 
 
@@ -205,6 +207,11 @@ def test_full_visibility_fast_paths_equal_the_general_ones():
     a, b = dense_to_observations(x, None), dense_to_observations(x, np.ones((57, 6), bool))
     for u, v in zip(a, b):
         assert u.dtype == v.dtype and np.array_equal(u, v)
+    # the reference caller's array, np.stack(x_list).transpose(1, 0, 2): its memory (the image planes) is handed on as it is
+    xs = np.stack([np.ascontiguousarray(x[:, k]) for k in range(6)]).transpose(1, 0, 2)
+    p, c, planes = dense_to_observations(xs, None)
+    assert planes.shape == (6, 57, 2) and np.shares_memory(planes, xs) and planes.flags.c_contiguous
+    assert np.array_equal(p, a[0]) and np.array_equal(c, a[1]) and np.array_equal(planes.transpose(1, 0, 2).reshape(-1, 2), a[2])
     x_list = [x[:, k] for k in range(6)]
     ref = np.stack([np.column_stack([xi / 1.7, np.ones(len(xi))]) for xi in x_list]).transpose(1, 0, 2)  # the reference's form (:34-40)
     got = _create_data_matrix(x_list, 1.7)

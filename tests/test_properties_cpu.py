@@ -11,6 +11,8 @@ from _engines import HostOracleEngine
 
 class _OracleBA(BundleAdjuster):
     def _make_engine(self, n_points, n_images, pt_ptr, cam_idx, xy, f0, axis, **kw):
+        xy = np.asarray(xy)  # (image planes (m, N, 2) when the caller's x was a transposed stack: the oracle takes the list form)
+        xy = xy.transpose(1, 0, 2).reshape(-1, 2) if xy.ndim == 3 else xy
         return HostOracleEngine(n_points, n_images, pt_ptr, cam_idx, xy, f0, axis)
 
 

@@ -1,23 +1,22 @@
-#!/usr/bin/env python3
-"""mvba_create phase times (MVBA_CREATE_TIMING=1) at a given scene size, device-built against host-built Schur index.
-usage: python tools/time_create.py <points> <cameras> <visibility>      (config-4 per-GPU shard: 1250000 500 0.05)"""
+"""Wall time of mvba_create's stages (MVBA_CREATE_TRACE=1) for a fully visible scene handed over as image planes, and of the whole
+BundleAdjuster() around it.  python tools/time_create.py [points images]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "3d-reconstruction-from-multi-view-exp_amd"), ROOT]
-from lib.bundle_adjustment import BundleAdjuster
+
+os.environ["MVBA_CREATE_TRACE"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-reconstruction-from-multi-view-exp_amd"))
+import numpy as np
+from lib import _mvba
+from lib.bundle_adjustment import dense_to_observations
 from lib.synthetic import make_scene
 
-n, m, vis = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
-sc = make_scene(n, m, vis_p=vis)
-os.environ["MVBA_CREATE_TIMING"] = "1"
-for mode in ("device", "host"):
-    if mode == "host":
-        os.environ["MVBA_INDEX"] = "host"
+n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1_000_000, 12)
+sc = make_scene(n, m, vis_p=1.0, noise=1e-3)
+xs = np.ascontiguousarray(sc.xy.reshape(n, m, 2).transpose(1, 0, 2)).transpose(1, 0, 2)  # the caller's np.stack(x_list).transpose(1, 0, 2)
+for rep in range(3):
     t0 = time.perf_counter()
-    ba = BundleAdjuster.from_observations(sc.n_points, m, sc.pt_ptr, sc.cam_idx, sc.xy, sc.init_X, sc.init_K, sc.init_R, sc.init_t, axis=sc.axis)
-    dt = time.perf_counter() - t0
-    eng = ba._engine
-    eng.cost(); eng.linearize(); E1 = eng.try_step(1e-3)
-    print(f"{mode}-built index: {n} points x {m} cameras x {vis}: {sc.n_obs} observations, {eng.schur_info()}, from_observations {dt:.3f} s, "
-          f"first trial cost {E1!r}", flush=True)
-    del ba, eng
+    pt_ptr, cam, xy = dense_to_observations(xs, None)
+    t1 = time.perf_counter()
+    e = _mvba.HipEngine(n, m, pt_ptr, cam, xy, 1.0, sc.axis)
+    t2 = time.perf_counter()
+    print(f"run {rep}: dense_to_observations {1e3 * (t1 - t0):.1f} ms, HipEngine() {1e3 * (t2 - t1):.1f} ms", file=sys.stderr)
+    e.close()

@@ -49,7 +49,7 @@ def run(n_points=1_000_000, n_images=12, max_iter=30, tol=1e-2, noise=1e-3, quie
                                                         ("_euclidean_upgrading", "self-calibration: _euclidean_upgrading"),
                                                         ("_reconstruct_3d", "self-calibration: _reconstruct_3d"),
                                                         ("correct_world_coordinates", "self-calibration: correct_world_coordinates"))]
-    saved += [(PC._DeviceDepthLoop, "__init__", timed(PC._DeviceDepthLoop, "__init__", "self-calibration: upload of the observations (depth loop workspace)")),
+    saved += [(PC._DeviceDepthLoop, "from_images", timed(PC._DeviceDepthLoop, "from_images", "self-calibration: upload of the images, x assembled on the device (depth loop workspace)")),
               (PC._DeviceDepthLoop, "factorize", timed(PC._DeviceDepthLoop, "factorize", "self-calibration: final factorisation of x o z (on the device, no upload)"))]
     saved += [(BA, "dense_to_observations", timed(BA, "dense_to_observations", "BundleAdjuster(): dense_to_observations")),
               (BA, "to_gauge_frame", timed(BA, "to_gauge_frame", "BundleAdjuster(): to_gauge_frame")),
