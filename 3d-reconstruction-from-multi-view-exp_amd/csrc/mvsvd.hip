@@ -1144,6 +1144,17 @@ __global__ void k_group_scale(const double *__restrict__ part, int blocks, int n
   if (lane == 0) cs[g] = 1.0 / t;
 }
 
+// mvsvd_load_images: one image's coordinates [n_rows][2] (float or double, as the caller holds them) into its two columns of the
+// measurement matrix W^T [n_rows][2 m]   (ref lib/affine_camera_calibration.py:224-240: np.hstack(data_list))
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void k_image_cols(const S *__restrict__ xy, long long n_rows, int n, int col, T *__restrict__ W) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  T *o = W + i * n + col;
+  o[0] = (T)xy[2 * i];
+  o[1] = (T)xy[2 * i + 1];
+}
+
 // mvsvd_load_base_images: one image's pixel coordinates [n_rows][2] (doubles, as the caller holds them) into its three columns
 // of the base, homogeneous: (x / f0, y / f0, 1)   (ref lib/perspective_camera_calibration.py:34-40)
 template <typename T>
@@ -2180,6 +2191,7 @@ struct mvsvd_handle {
   void *dW = nullptr, *dS = nullptr;
   double *dG = nullptr, *dV = nullptr, *dV1 = nullptr, *dsum = nullptr, *dMr = nullptr, *dmu = nullptr, *dpart = nullptr, *dpart2 = nullptr, *dB = nullptr;
   int *dsw = nullptr;
+  void *dstage = nullptr;             // mvsvd_load_images: one image's [max_rows][2] array on its way into its two columns
   void *dX = nullptr, *dz = nullptr;  // mvsvd_load_base / mvsvd_run_scaled: resident base matrix, the depths of one call
   double *dgs = nullptr;              // column-group partial sums and scales
   bool base_loaded = false;
@@ -2830,7 +2842,7 @@ void mvsvd_destroy(mvsvd_handle *h) {
   hipSetDevice(h->device);
   if (h->st) hipStreamSynchronize(h->st);
   for (void *p : {h->dW, h->dS, (void *)h->dG, (void *)h->dV, (void *)h->dV1, (void *)h->dsum, (void *)h->dMr, (void *)h->dmu,
-                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, (void *)h->dgs, (void *)h->ddep, (void *)h->ddflag,
+                  (void *)h->dsw, (void *)h->dpart, (void *)h->dpart2, (void *)h->dB, h->dX, h->dz, h->dstage, (void *)h->dgs, (void *)h->ddep, (void *)h->ddflag,
                   (void *)h->dQ, (void *)h->dZ, (void *)h->dQ2, (void *)h->dBw, (void *)h->dB2, (void *)h->dzpart, (void *)h->dsmall, (void *)h->dwflag})
     if (p) hipFree(p);
   for (auto &e : h->ev)
@@ -2853,6 +2865,41 @@ int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows) {
   h->n_rows = n_rows;
   h->loaded = true;
   h->wide_warm = h->wide_have_q = false;  // a new matrix: the block iteration starts from its fixed block
+  return MVBA_OK;
+}
+
+int mvsvd_load_images(mvsvd_handle *h, const void *const *xy, int32_t n_images, int64_t n_rows, int32_t src_dtype) {
+  if (!h || !xy) return fail(MVBA_ERR_BADARG, "null argument");
+  if (n_rows < 1 || n_rows > h->max_rows) return fail(MVBA_ERR_BADARG, "n_rows outside the workspace (1 .. max_rows)");
+  if (n_images < 1 || 2 * (long long)n_images != h->n) return fail(MVBA_ERR_BADARG, "the workspace must have 2 columns per image");
+  if (src_dtype != 0 && src_dtype != 1) return fail(MVBA_ERR_BADARG, "src_dtype must be 0 (float32) or 1 (float64)");
+  for (int k = 0; k < n_images; ++k)
+    if (!xy[k]) return fail(MVBA_ERR_BADARG, "null image array");
+  MVBA_HIP(hipSetDevice(h->device));
+  if (!h->dstage) MVBA_HIP(hipMalloc(&h->dstage, 16 * (size_t)h->max_rows));
+  const size_t bytes = (src_dtype ? 16 : 8) * (size_t)n_rows;
+  const unsigned grid = (unsigned)((n_rows + 255) / 256);
+  hipEventRecord(h->ev[0], h->st);
+  for (int k = 0; k < n_images; ++k) {  // image after image in stream order through the one staging buffer
+    MVBA_HIP(hipMemcpyAsync(h->dstage, xy[k], bytes, hipMemcpyHostToDevice, h->st));
+    if (src_dtype == 0 && h->dtype == 0)
+      hipLaunchKernelGGL((k_image_cols<float, float>), dim3(grid), dim3(256), 0, h->st, (const float *)h->dstage, (long long)n_rows, h->n, 2 * k, (float *)h->dW);
+    else if (src_dtype == 0)
+      hipLaunchKernelGGL((k_image_cols<float, double>), dim3(grid), dim3(256), 0, h->st, (const float *)h->dstage, (long long)n_rows, h->n, 2 * k, (double *)h->dW);
+    else if (h->dtype == 0)
+      hipLaunchKernelGGL((k_image_cols<double, float>), dim3(grid), dim3(256), 0, h->st, (const double *)h->dstage, (long long)n_rows, h->n, 2 * k, (float *)h->dW);
+    else
+      hipLaunchKernelGGL((k_image_cols<double, double>), dim3(grid), dim3(256), 0, h->st, (const double *)h->dstage, (long long)n_rows, h->n, 2 * k, (double *)h->dW);
+  }
+  hipEventRecord(h->ev[1], h->st);
+  MVBA_HIP(hipGetLastError());
+  MVBA_HIP(hipStreamSynchronize(h->st));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+  h->h2d_ms = ms;
+  h->n_rows = n_rows;
+  h->loaded = true;
+  h->wide_warm = h->wide_have_q = false;
   return MVBA_OK;
 }
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mvsvd_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "mvsvd_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mvsvd_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
+    "mvsvd_load_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32]),
     "mvsvd_load_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mvsvd_load_base_images": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_double]),
     "mvsvd_run_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp]),
@@ -346,6 +347,21 @@ class SvdWorkspace:
         self.n_rows = Wt.shape[0]
         return self
 
+    def load_images(self, x_list):
+        """The matrix np.hstack(x_list) (n_rows, 2 m) put together on the device from the images' (n_rows, 2) arrays themselves
+        (all float32 or all float64; converted to the workspace's dtype)."""
+        src = np.result_type(*x_list)
+        if src not in (np.float32, np.float64):
+            raise ValueError("image arrays must be float32 or float64")
+        arrs = [np.ascontiguousarray(a, dtype=src) for a in x_list]
+        n_rows = arrs[0].shape[0]
+        if 2 * len(arrs) != self.n_cols or any(a.shape != (n_rows, 2) for a in arrs):
+            raise ValueError("x_list must hold n_cols / 2 arrays of shape (n_rows, 2)")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        raise_for(self.lib.mvsvd_load_images(self._h, ptrs, len(arrs), n_rows, 0 if src == np.float32 else 1), self.lib)
+        self.n_rows = n_rows
+        return self
+
     def load_base(self, X):
         """The resident base matrix of run_scaled (one upload for a whole depth loop)."""
         X = np.ascontiguousarray(X, dtype=self.dtype)
@@ -439,6 +455,46 @@ def _svd_cache_clear():
 svd_cache_clear = _svd_cache_clear  # public name: call it to hand the cached workspaces' device memory back (e.g. before a large BundleAdjuster)
 
 
+def _svd_cache_usable(n_rows, n_cols, n_rank):
+    return os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 12288
+
+
+def _svd_cached_run(dtype, n_rows, n_cols, device, load, n_rank, center):
+    """`load(ws)` then `ws.run(n_rank, center)` on the cached workspace of (dtype, n_cols, device), made or grown as needed."""
+    global _svd_cache_atexit
+    dtype = np.dtype(dtype)
+    key = (dtype.str, n_cols, int(device))
+    with _svd_cache_lock:  # (held through the call: a workspace is one matrix and one stream)
+        ws = _svd_cache.get(key)
+        if ws is None or ws.max_rows < n_rows:
+            old = _svd_cache.pop(key, None)  # out of the cache BEFORE it is closed: a failing allocation below must not leave a closed handle behind
+            if old is not None:
+                old.close()
+            if not _svd_cache_atexit:
+                import atexit
+
+                atexit.register(_svd_cache_clear)
+                _svd_cache_atexit = True
+            ws = SvdWorkspace(n_rows, n_cols, dtype, device)
+            _svd_cache[key] = ws
+        load(ws)
+        return ws.run(n_rank, center)
+
+
+def svd_factorize_images(x_list, n_rank, center=False, device=-1):
+    """`svd_factorize(np.hstack(x_list), ...)` without the hstack: the images' (n_rows, 2) arrays (all float32 or all float64) go to
+    the device as they are and the (n_rows, 2 m) matrix is put together there (`mvsvd_load_images`).  Anything else -- other
+    dtypes, ragged lists, the cache switched off -- takes the host's hstack."""
+    if device_count() < 1:
+        raise RuntimeError("libmvba: no HIP device visible; the SVD kernel has no CPU fallback")
+    arrs = [np.asarray(a) for a in x_list]
+    n_rows, n_cols = (arrs[0].shape[0] if arrs and arrs[0].ndim == 2 else 0), 2 * len(arrs)
+    dt = np.result_type(*arrs) if arrs else np.dtype(np.float64)
+    if (dt in (np.float32, np.float64) and all(a.shape == (n_rows, 2) for a in arrs) and _svd_cache_usable(n_rows, n_cols, n_rank)):
+        return _svd_cached_run(dt, n_rows, n_cols, device, lambda ws: ws.load_images(arrs), n_rank, center)
+    return svd_factorize(np.ascontiguousarray(np.hstack(arrs)), n_rank, center, device)
+
+
 def svd_factorize(Wt, n_rank, center=False, device=-1):
     """Thin SVD of W = Wt^T.  Wt: (n_rows, n_cols) float32/float64, C-contiguous.
     Returns M (n_cols, r), sigma (n_cols,), S (r, n_rows), means (n_cols,), timings.
@@ -453,23 +509,8 @@ def svd_factorize(Wt, n_rank, center=False, device=-1):
     if Wt.dtype not in (np.float32, np.float64):
         Wt = Wt.astype(np.float64)
     n_rows, n_cols = Wt.shape
-    if os.environ.get("MVBA_SVD_CACHE", "1") != "0" and n_rows >= 1 and 1 <= n_rank <= n_cols <= 12288:
-        global _svd_cache_atexit
-        key = (Wt.dtype.str, n_cols, int(device))
-        with _svd_cache_lock:  # (held through the call: a workspace is one matrix and one stream)
-            ws = _svd_cache.get(key)
-            if ws is None or ws.max_rows < n_rows:
-                old = _svd_cache.pop(key, None)  # out of the cache BEFORE it is closed: a failing allocation below must not leave a closed handle behind
-                if old is not None:
-                    old.close()
-                if not _svd_cache_atexit:
-                    import atexit
-
-                    atexit.register(_svd_cache_clear)
-                    _svd_cache_atexit = True
-                ws = SvdWorkspace(n_rows, n_cols, Wt.dtype, device)
-                _svd_cache[key] = ws
-            return ws.load(Wt).run(n_rank, center)
+    if _svd_cache_usable(n_rows, n_cols, n_rank):
+        return _svd_cached_run(Wt.dtype, n_rows, n_cols, device, lambda ws: ws.load(Wt), n_rank, center)
     M = np.empty((n_cols, n_rank), Wt.dtype)
     sigma = np.empty(n_cols, Wt.dtype)
     S = np.empty((n_rank, n_rows), Wt.dtype)

@@ -143,14 +143,15 @@ def _svd_on_gpu(data_list, mirror=False):
     """Centred thin SVD of the measurement matrix through libmvba (rank 3).  Signs: largest-magnitude
     entry of each column of U positive; `mirror=True` flips the third triplet (the other sign parity:
     the mirror-image reconstruction, see the module docstring)."""
-    from ._mvba import svd_factorize
+    from ._mvba import svd_factorize_images
 
     n = {len(x) for x in data_list}
     if len(n) != 1:
         raise ValueError()
-    Wt = np.ascontiguousarray(np.hstack(data_list))  # (N, 2m): exactly the array the reference transposes
-    U3, _sigma, S3, mu, _tm = svd_factorize(Wt, 3, center=True)
-    U3, S3 = U3.astype(np.float64), S3.astype(np.float64)
+    # W^T = np.hstack(data_list) (N, 2m), exactly the array the reference transposes (:224-240), is put together on the device from
+    # the images' own arrays: the hstack on the host was 0.3 s at 5 M points x 12 images, the upload + factorisation 0.015
+    U3, _sigma, S3, mu, _tm = svd_factorize_images(data_list, 3, center=True)
+    U3, S3 = U3.astype(np.float64), S3.astype(np.float64, copy=False)
     if mirror:
         U3[:, 2] *= -1.0
         S3[2] *= -1.0

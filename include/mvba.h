@@ -218,6 +218,11 @@ int mvsvd_factorize(const void *Wt, int64_t n_rows, int32_t n_cols, int32_t dtyp
 typedef struct mvsvd_handle mvsvd_handle;
 int mvsvd_create(int64_t max_rows, int32_t n_cols, int32_t dtype, int32_t device, mvsvd_handle **out);
 int mvsvd_load(mvsvd_handle *h, const void *Wt, int64_t n_rows);
+/* The same matrix put together on the device from the images' own arrays -- what the reference's callers hold
+ * (ref lib/affine_camera_calibration.py:224-240: W = np.hstack(data_list).T; the hstack alone is 0.3 s of strided host writes at
+ * 5 M points x 12 images, twenty times the upload + factorisation): xy[k] = image k's coordinates [n_rows][2], float32
+ * (src_dtype 0) or float64 (1), converted to the workspace's dtype; W^T[i][2k .. 2k+1] = xy[k][i]; n_cols must be 2 n_images. */
+int mvsvd_load_images(mvsvd_handle *h, const void *const *xy, int32_t n_images, int64_t n_rows, int32_t src_dtype);
 int mvsvd_run(mvsvd_handle *h, int32_t n_rank, int32_t center, void *M, void *sigma, void *S, void *means,
               double *timings_ms);
 

@@ -566,6 +566,36 @@ def test_depth_iteration_in_float32():
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_measurement_matrix_put_together_on_the_device_equals_the_host_hstack(dtype):
+    """`svd_factorize_images(x_list, ...)` (`mvsvd_load_images`: the images' (N, 2) arrays as they are) against
+    `svd_factorize(np.hstack(x_list), ...)` (ref lib/affine_camera_calibration.py:224-240): the same matrix on the device, so
+    bitwise the same factors, centred or not; a non-contiguous image, mixed float32/float64 lists (promoted, as np.hstack does) and
+    lists the device path does not take (integers, ragged) give what the host form gives."""
+    rng = np.random.default_rng(41)
+    n, m = 7001, 9
+    x_list = [rng.uniform(-300, 300, (n, 2)).astype(dtype) for _ in range(m)]
+    x_list[4] = np.asfortranarray(x_list[4])
+    for center in (False, True):
+        a = _mvba.svd_factorize(np.ascontiguousarray(np.hstack(x_list)), 3, center=center)
+        b = _mvba.svd_factorize_images(x_list, 3, center=center)
+        for u, v in zip(a[:4], b[:4]):
+            assert u.dtype == v.dtype == dtype and np.array_equal(u, v, equal_nan=True)
+    mixed = [x.astype(np.float32) if k % 2 else x.astype(np.float64) for k, x in enumerate(x_list)]
+    a, b = _mvba.svd_factorize(np.ascontiguousarray(np.hstack(mixed)), 3), _mvba.svd_factorize_images(mixed, 3)
+    assert b[0].dtype == np.float64 and all(np.array_equal(u, v, equal_nan=True) for u, v in zip(a[:3], b[:3]))
+    ints = [np.rint(x).astype(np.int64) for x in x_list]
+    a, b = _mvba.svd_factorize(np.hstack(ints), 3), _mvba.svd_factorize_images(ints, 3)
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(a[:3], b[:3]))
+    with pytest.raises(ValueError):
+        _mvba.svd_factorize_images(x_list[:-1] + [x_list[0][:-1]], 3)  # ragged: np.hstack's own error
+    ws = _mvba.SvdWorkspace(n, 2 * m, dtype)
+    with pytest.raises(ValueError):
+        ws.load_images(x_list[:-1])
+    ws.close()
+    _mvba.svd_cache_clear()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_base_assembled_on_the_device_equals_the_host_data_matrix(dtype):
     """`mvsvd_load_base_images` (the images' (N, 2) arrays as they are; x / f0, y / f0, 1 formed on the device) against
     `mvsvd_load_base` of `_create_data_matrix`'s array (ref :34-40): the same base bit for bit -- an IEEE division either way --
