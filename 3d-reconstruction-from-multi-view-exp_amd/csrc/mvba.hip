@@ -1293,7 +1293,10 @@ __device__ __forceinline__ int dense_tile_elem(int row, int col) { return ((row 
 
 constexpr int dense_pair_ti(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a; }
 constexpr int dense_pair_tj(int p, int T) { int a = 0; while (p >= T - a) { p -= T - a; ++a; } return a + p; }
-constexpr int dense_consumers(int T) { return T <= 8 ? 4 : 8; }  // consumer waves: at most ~10 tile pairs (40 accumulator doubles) each
+#ifndef MVBA_DENSE_NC_SMALL
+#define MVBA_DENSE_NC_SMALL 4
+#endif
+constexpr int dense_consumers(int T) { return T <= 8 ? MVBA_DENSE_NC_SMALL : 8; }  // consumer waves: at most ~10 tile pairs (40 accumulator doubles) each
 constexpr bool dense_tile_used(int u, int T, int wave) {  // does consumer wave `wave` own a pair with tile u?
   const int P = T * (T + 1) / 2, NC = dense_consumers(T);
   for (int p = wave; p < P; p += NC)
@@ -1343,7 +1346,7 @@ __device__ __forceinline__ void dense_main_mfma(const double *sG, const double *
 // lockstep and the phases never overlapped: 1.55 ms at 1 M x 12 for 0.81 ms of MFMA phase; with four producer waves of two points
 // each the producers were the longer role: 1.90 ms.)
 template <int T, bool TABLE>  // TABLE: the records of a point through obs_of (missing observations), otherwise one contiguous range
-__global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
+__global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2))) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
                                                      long long N, int m, double cu, double *__restrict__ part) {
   constexpr int NC = dense_consumers(T);           // consumer waves (4 + 8 producers up to 8 tiles, 8 + 4 beyond)
   constexpr int P = T * (T + 1) / 2, NPW = (P + NC - 1) / NC, W = 16 * T, NCW = ((16 * T) / 9 + NC - 1) / NC;
@@ -1368,45 +1371,56 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
     const int pw = wave - NC;
     double2 *sR = sScr + (size_t)pw * (m * REC + 8), *sP = sR + (size_t)m * REC;
     constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 10 + 63) / 64;
-    double2 pre[NPRE], prepb;
-    int oid[NPRE], oid_next[NPRE];                 // (obs_of != nullptr) the observations of this chunk's / the next chunk's point
+    // TWO chunks' records in flight per wave (sets A and B, used in turn): with one, a CU had 8 waves x 1.5 KB outstanding against
+    // ~2 us of loaded memory latency -- 1.5 TB/s over the chip, which is where the kernel sat at every camera count (~1.0 ms per
+    // million points x 12 cameras whatever the matrix cores had to do)
+    double2 preA[NPRE], prepbA, preB[NPRE], prepbB;
+    bool lvA, lvB;
+    int oidA[NPRE], oidB[NPRE], oid_next[NPRE];    // (obs_of != nullptr) the observations of a set's point / of the point fetched next
     double *sF = sFlag + (size_t)pw * m;
     auto fetch_ids = [&](long long ch) {           // the table row of chunk ch's point (one entry per record: eight lanes share it)
       const long long a = ch * CH + pw;
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int e = lane + 64 * u;
-        oid_next[u] = (a < N && e < m * REC) ? obs_of[(size_t)a * m + (e >> 3)] : -1;
+        const int got = obs_of[(size_t)min(a, N - 1) * m + min(e >> 3, m - 1)], msk = (a < N && e < m * REC) ? -1 : 0;
+        oid_next[u] = (got & msk) | ~msk;          // (-1 outside; the load itself is unconditional, see fetch)
       }
     };
-    auto fetch = [&](long long ch) {               // this wave's records and point row of chunk ch (zeros past the last point)
+    auto fetch = [&](long long ch, double2 (&pre)[NPRE], int (&oid)[NPRE], double2 &prepb, bool &lv) {  // this wave's records and point row of chunk ch (zeros past the last point)
+      // The loads are UNCONDITIONAL on clamped addresses and what must be zero (a missing observation, a point past the end) is
+      // zeroed on the bit pattern in build(): behind a lane-dependent branch the compiler cannot count the loads in flight and
+      // waits for all of them (vmcnt(0)) -- the other set's too, which is the one meant to stay in flight
       const long long a = ch * CH + pw;
-      const bool live = a < N;
-      if (TABLE) {                                 // through the table read a chunk earlier: a missing observation is a zero record
+      const bool live = lv = a < N;
+      if (TABLE) {                                 // through the table read a chunk earlier
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
           oid[u] = oid_next[u];
-          pre[u] = oid[u] >= 0 ? rec[(size_t)oid[u] * REC + ((lane + 64 * u) & 7)] : double2{0.0, 0.0};
+          pre[u] = rec[(size_t)max(oid[u], 0) * REC + ((lane + 64 * u) & 7)];
         }
       } else {
         const double2 *src = rec + (size_t)min(a, N - 1) * m * REC;
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
-          const int e = lane + 64 * u;
-          pre[u] = (live && e < m * REC) ? src[e] : double2{0.0, 0.0};
+          pre[u] = src[min(lane + 64 * u, m * REC - 1)];
           oid[u] = live ? 0 : -1;
         }
       }
-      prepb = (live && lane < 8) ? reinterpret_cast<const double2 *>(PB + (size_t)min(a, N - 1) * PBS)[lane] : double2{0.0, 0.0};
+      prepb = reinterpret_cast<const double2 *>(PB + (size_t)min(a, N - 1) * PBS)[lane & 7];
     };
-    auto build = [&](int buf) {                    // registers -> the rows of G and the camera rows of this wave's point in buffer `buf`
+    auto keep = [](bool c, double2 v) -> double2 {  // c ? v : 0 without a branch the load could sink under
+      const long long msk = c ? -1LL : 0LL;
+      return double2{__longlong_as_double(__double_as_longlong(v.x) & msk), __longlong_as_double(__double_as_longlong(v.y) & msk)};
+    };
+    auto build = [&](int buf, const double2 (&pre)[NPRE], const int (&oid)[NPRE], const double2 &prepb, bool lv) {  // registers -> the rows of G and the camera rows of this wave's point in buffer `buf`
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int e = lane + 64 * u;
-        if (e < m * REC) sR[e] = pre[u];
+        if (e < m * REC) sR[e] = keep(oid[u] >= 0, pre[u]);
         if (e < m * REC && (e & 7) == 0) sF[e >> 3] = oid[u] >= 0 ? 1.0 : 0.0;
       }
-      if (lane < 8) sP[lane] = prepb;
+      sP[lane & 7] = keep(lv, prepb);             // (every lane, eight copies of each slot: a store under `lane < 8` drew a vmcnt(0))
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       // point row: E^-1 (6) | E^-1 dP (3) | sign code | R lower triangular (r00 r10 r20 r11 r21 r22) of E^-1 = R S R^T (k_point_inv), the same for every lane
@@ -1442,24 +1456,32 @@ __global__ __launch_bounds__(768) void k_schur_dense(const double2 *__restrict__
       }
     };
     long long ch = blockIdx.x;
+    const long long gs = gridDim.x;
+    // (a fetch past the last chunk loads nothing: zero records nobody reads; fetch_ids likewise -1)
     if (TABLE) fetch_ids(ch);
-    fetch(ch);
-    if (TABLE) fetch_ids(ch + gridDim.x);         // (past the last chunk: -1, zero records nobody reads)
-    build(0);
-    if (ch + gridDim.x < n_chunks) {
-      fetch(ch + gridDim.x);
-      if (TABLE) fetch_ids(ch + 2 * (long long)gridDim.x);
-    }
+    fetch(ch, preA, oidA, prepbA, lvA);
+    if (TABLE) fetch_ids(ch + gs);
+    fetch(ch + gs, preB, oidB, prepbB, lvB);
+    if (TABLE) fetch_ids(ch + 2 * gs);
+    build(0, preA, oidA, prepbA, lvA);
+    fetch(ch + 2 * gs, preA, oidA, prepbA, lvA);
+    if (TABLE) fetch_ids(ch + 3 * gs);
     __syncthreads();
-    for (int b = 0; ch < n_chunks; ch += gridDim.x, b ^= 1) {
-      if (ch + gridDim.x < n_chunks) {
-        build(b ^ 1);
-        if (ch + 2 * (long long)gridDim.x < n_chunks) {
-          fetch(ch + 2 * (long long)gridDim.x);
-          if (TABLE) fetch_ids(ch + 3 * (long long)gridDim.x);
-        }
-      }
+    // One barrier per chunk, as the consumers; the sets alternate: B holds chunk ch + 1, A chunk ch + 2.  Nothing in the body is
+    // conditional (behind `if (ch + gs < n_chunks)` the compiler lost count of the loads in flight and waited vmcnt(0) for both
+    // sets): past the last chunk a build writes a chunk of zeros into the buffer nobody reads any more.
+    for (int b = 0; ch < n_chunks;) {
+      build(b ^ 1, preB, oidB, prepbB, lvB);
+      fetch(ch + 3 * gs, preB, oidB, prepbB, lvB);
+      if (TABLE) fetch_ids(ch + 4 * gs);
       __syncthreads();
+      ch += gs, b ^= 1;
+      if (ch >= n_chunks) break;
+      build(b ^ 1, preA, oidA, prepbA, lvA);
+      fetch(ch + 3 * gs, preA, oidA, prepbA, lvA);
+      if (TABLE) fetch_ids(ch + 4 * gs);
+      __syncthreads();
+      ch += gs, b ^= 1;
     }
     return;
   }
@@ -4649,7 +4671,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         h->dense_attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * ((T <= 8 ? 4 : 8) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (const int *)h->d_dense_obs,
+      hipLaunchKernelGGL(kern, dim3(h->dense_blocks), dim3(64 * (dense_consumers(T) + CH)), lds, h->stream, (const double2 *)h->d_rec, (const double *)h->d_PB, (const int *)h->d_dense_obs,
                          (long long)h->N, m, 1.0 / h->f0, h->d_dense_part);
     };
     const bool table = h->d_dense_obs != nullptr;
