@@ -1345,6 +1345,13 @@ __device__ __forceinline__ void dense_main_mfma(const double *sG, const double *
 // among themselves.  (With every wave doing every phase in turn -- four barriers per chunk -- the workgroups of a CU ran in
 // lockstep and the phases never overlapped: 1.55 ms at 1 M x 12 for 0.81 ms of MFMA phase; with four producer waves of two points
 // each the producers were the longer role: 1.90 ms.)
+#ifdef MVBA_DENSE_TRACE  // (timing-only build, tools/dense_trace.sh: where a role's time goes -- work or the chunk barrier)
+__device__ long long g_dense_trace[1024 * 16 * 4];  // per workgroup and wave: role work, barrier wait, total, chunks (shader clock)
+#define DT_NOW() ((long long)__builtin_readcyclecounter())
+#define DT_BARRIER() do { const long long t0_ = DT_NOW(); __syncthreads(); dt_wait += DT_NOW() - t0_; } while (0)
+#else
+#define DT_BARRIER() __syncthreads()
+#endif
 template <int T, bool TABLE>  // TABLE: the records of a point through obs_of (missing observations), otherwise one contiguous range
 __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2))) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
                                                      long long N, int m, double cu, double *__restrict__ part) {
@@ -1369,6 +1376,13 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
     // ---------------- producer: point pw of every chunk of this workgroup.  (Without the staging -- a lane per (camera, column)
     // fetching its four record slots itself -- the per-lane loads cost more than the staging saves: 1.82 against 1.40 ms.)
     const int pw = wave - NC;
+#ifndef MVBA_DENSE_PRIO
+#define MVBA_DENSE_PRIO 1
+#endif
+    // The producers are the longer role (tools/dense_trace.py: 5,350 cycles of work per chunk against the consumers' 4,480 + 1,400 at
+    // the barrier, 1 M x 12) and, as the later-dispatched waves of their SIMD, the losers of its issue arbitration (older first at
+    // equal priority): they ask for the higher priority once, here.
+    if (MVBA_DENSE_PRIO) __builtin_amdgcn_s_setprio(MVBA_DENSE_PRIO);
     double2 *sR = sScr + (size_t)pw * (m * REC + 8), *sP = sR + (size_t)m * REC;
     constexpr int NPRE = (MMAX * REC + 63) / 64, NIT = (MMAX * 10 + 63) / 64;
     // TWO chunks' records in flight per wave (sets A and B, used in turn): with one, a CU had 8 waves x 1.5 KB outstanding against
@@ -1466,7 +1480,11 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
     build(0, preA, oidA, prepbA, lvA);
     fetch(ch + 2 * gs, preA, oidA, prepbA, lvA);
     if (TABLE) fetch_ids(ch + 3 * gs);
-    __syncthreads();
+#ifdef MVBA_DENSE_TRACE
+    long long dt_wait = 0, dt_n = 0;
+    const long long dt_t0 = DT_NOW();
+#endif
+    DT_BARRIER();
     // One barrier per chunk, as the consumers; the sets alternate: B holds chunk ch + 1, A chunk ch + 2.  Nothing in the body is
     // conditional (behind `if (ch + gs < n_chunks)` the compiler lost count of the loads in flight and waited vmcnt(0) for both
     // sets): past the last chunk a build writes a chunk of zeros into the buffer nobody reads any more.
@@ -1474,15 +1492,28 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
       build(b ^ 1, preB, oidB, prepbB, lvB);
       fetch(ch + 3 * gs, preB, oidB, prepbB, lvB);
       if (TABLE) fetch_ids(ch + 4 * gs);
-      __syncthreads();
+      DT_BARRIER();
       ch += gs, b ^= 1;
+#ifdef MVBA_DENSE_TRACE
+      ++dt_n;
+#endif
       if (ch >= n_chunks) break;
       build(b ^ 1, preA, oidA, prepbA, lvA);
       fetch(ch + 3 * gs, preA, oidA, prepbA, lvA);
       if (TABLE) fetch_ids(ch + 4 * gs);
-      __syncthreads();
+      DT_BARRIER();
       ch += gs, b ^= 1;
+#ifdef MVBA_DENSE_TRACE
+      ++dt_n;
+#endif
     }
+#ifdef MVBA_DENSE_TRACE
+    if (lane == 0 && blockIdx.x < 1024) {
+      long long *tr = g_dense_trace + ((size_t)blockIdx.x * 16 + wave) * 4;
+      const long long tot = DT_NOW() - dt_t0;
+      tr[0] = tot - dt_wait; tr[1] = dt_wait; tr[2] = tot; tr[3] = dt_n;
+    }
+#endif
     return;
   }
   // ---------------- consumer: tile pairs NC q + wave of the upper triangle (row-major), cameras NC q + wave
@@ -1491,7 +1522,11 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
   for (int q = 0; q < NPW; ++q) acc[q] = mvba_d4{0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < NCW; ++q) cacc[q] = mvba_d4{0, 0, 0, 0};
-  __syncthreads();  // chunk 0 is built
+#ifdef MVBA_DENSE_TRACE
+  long long dt_wait = 0, dt_n = 0;
+  const long long dt_t0 = DT_NOW();
+#endif
+  DT_BARRIER();  // chunk 0 is built
   int b = 0;
   for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
     const double *bG = sG + (size_t)b * 3 * CH * W, *bB = sB + (size_t)b * CH * m * 32, *bS = sSgn + (size_t)b * 3 * CH;
@@ -1519,8 +1554,18 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
       }
     }
 #endif
-    __syncthreads();  // this chunk's buffers may be rebuilt, the next chunk's are complete
+    DT_BARRIER();  // this chunk's buffers may be rebuilt, the next chunk's are complete
+#ifdef MVBA_DENSE_TRACE
+    ++dt_n;
+#endif
   }
+#ifdef MVBA_DENSE_TRACE
+  if (lane == 0 && blockIdx.x < 1024) {
+    long long *tr = g_dense_trace + ((size_t)blockIdx.x * 16 + wave) * 4;
+    const long long tot = DT_NOW() - dt_t0;
+    tr[0] = tot - dt_wait; tr[1] = dt_wait; tr[2] = tot; tr[3] = dt_n;
+  }
+#endif
   double *out = part + (size_t)blockIdx.x * (P + m) * 256;
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
@@ -3463,6 +3508,11 @@ __global__ __launch_bounds__(256) void k_xy_from_planes(const double2 *__restric
 }  // namespace
 
 extern "C" {
+#ifdef MVBA_DENSE_TRACE
+int mvba_dense_trace_read(long long *out, int n) {  // (timing-only build)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_trace), sizeof(long long) * n, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+}
+#endif
 #ifdef MVBA_BS_TRACE
 int mvba_debug_bs_trace(long long *out /* [8 * 256] */) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_trace), sizeof(long long) * 8 * 256) == hipSuccess ? 0 : 1;
