@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2)
   double2 *sScr = reinterpret_cast<double2 *>(sB + (size_t)2 * CH * m * 32);  // per producer wave: records [m][8], point row [8]
   double *sFlag = reinterpret_cast<double *>(sScr + (size_t)CH * (m * REC + 8));  // per producer wave: [m] 1 for an observation, 0 for a missing one
   double *sSgn = sFlag + (size_t)CH * m;                            // [2][3 CH]: the signs of the rows of G
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;  // (wave through readfirstlane -- scalar address arithmetic for the producers -- made every shape slower: 1.36 -> 1.55 ms at 1 M x 12, 2.95 -> 12.6 at 20 cameras)
   const long long n_chunks = (N + CH - 1) / CH;
   // what no phase ever writes stays zero: the columns of G beyond 9 m, the columns 10..15 of the camera rows
   for (int e = threadIdx.x; e < 2 * 3 * CH * W; e += NTHR) sG[e] = 0.0;
