@@ -11,11 +11,16 @@ trial cost, commit; the LM control flow is the reference's own
 
 N = 1   BASELINE config 3: 1M points x 100 cameras, 10 % visibility (the configuration the
         metric is quoted on).
-N > 1   (one process per GPU)  BASELINE config 4: 10M points x 500 cameras, 5 % visibility,
-        STRONG scaling -- the fixed global scene is split by point id into N observation-balanced
-        shards, one RCCL all-reduce of the packed reduced camera system per LM solve.
-        `value` = plain it/s of the whole job.  `--weak` instead gives every rank a
-        config-3-sized shard (round-1 behaviour).
+N > 1   (one process per GPU)  WEAK scaling of that same workload: every rank holds a config-3-sized
+        point shard (1M points of an N x 1M-point scene; the 100 cameras are replicated), one RCCL
+        all-reduce of the packed reduced camera system per LM solve.  `value` = the units all ranks
+        processed / time = N x (LM iterations per second of the joint problem), one unit being an LM
+        iteration over one config-3-sized shard -- so that the per-N values of one series measure one
+        thing and `value(N) / (N value(1))` is the efficiency (`config.joint_it_per_s` is the plain rate).
+        `--strong` instead runs BASELINE config 4 (10M points x 500 cameras, 5 % visibility) split by
+        point id into N observation-balanced shards, `value` = plain it/s of the whole job -- a series
+        of its own whose N = 1 point is `--config4` (rounds 2-5 made this the N > 1 default, which put
+        two different workloads into the driver's N = 1, 2, 4, 8 series).
         Started either by a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py
         --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or
         plainly as `python bench.py --gpus N ...`: with no WORLD_SIZE in the environment the
@@ -536,7 +541,8 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="global points (default: 1M at N=1, 10M at N>1)")
     ap.add_argument("--cams", type=int, default=None)
     ap.add_argument("--vis", type=float, default=None)
-    ap.add_argument("--weak", action="store_true", help="N>1: a config-3-sized shard per GPU instead of config 4 split N ways")
+    ap.add_argument("--weak", action="store_true", help="N>1: a config-3-sized shard per GPU (the default; kept for old command lines)")
+    ap.add_argument("--strong", action="store_true", help="N>1: BASELINE config 4 (10M points x 500 cameras x 5 %%) split N ways instead")
     ap.add_argument("--config4", action="store_true",
                     help="N=1: run config 4 (10M points x 500 cameras x 5 %%, 250M observations) on the one GPU -- the N=1 point of "
                          "the config-4 scaling curve; needs ~80 GB of HBM and a few minutes of index building")
@@ -595,7 +601,7 @@ def main():
     from lib.bundle_adjustment import BundleAdjuster, LevenbergMarquardt
     from lib.synthetic import make_scene, scene_shard
 
-    config4 = (world > 1 and not args.weak) or args.config4
+    config4 = (world > 1 and args.strong and not args.weak) or args.config4
     shard4 = args.config4_shard and world == 1 and not args.config4
     n_cams = args.cams or (500 if config4 or shard4 else 100)
     vis = args.vis or (0.05 if config4 or shard4 else 0.1)
@@ -611,8 +617,8 @@ def main():
         scaling, cfg_name = "weak", "BASELINE config 3" + (" shard per GPU" if world > 1 else "")
         if shard4:
             cfg_name = "BASELINE config 4, ONE of its 8 point shards on one GPU (no exchange)"
-        elif world == 1 and (args.points or args.cams or args.vis):
-            cfg_name = "custom scene (not a BASELINE config)"
+        elif args.points or args.cams or args.vis:
+            cfg_name = "custom scene (not a BASELINE config)" + (", one shard per GPU" if world > 1 else "")
     t_gen = time.perf_counter()
     sc = make_scene(n_total, n_cams, vis_p=vis, point_range=(lo, hi))
     t_gen = time.perf_counter() - t_gen
@@ -764,7 +770,9 @@ def main():
                 "points_total": n_total, "points_rank0": sc.n_points, "cameras": n_cams, "visibility": vis,
                 "observations_total": n_obs_total, "reduced_system_dim": 9 * n_cams - 7,
                 "value_definition": "outer LM iterations per second of the whole job"
-                                    + (" x point shards (weak scaling: every rank holds a config-3 shard)" if scaling == "weak" and world > 1 else ""),
+                                    + (" x point shards (weak scaling: every rank holds a config-3-sized shard; one unit = one LM iteration over one "
+                                       "such shard, value = the units all ranks processed / time)" if scaling == "weak" and world > 1 else ""),
+                "joint_it_per_s": args.steps / dt,
                 "episode_iterations": EPISODE, "episode_restarts_in_timed_region": n_restarts - restarts0,
                 "scene_generation_s": t_gen, "engine_create_s": t_create,
                 "parallelism": f"point shards x{world}" + ("" if not multi else (", host-staged all-reduce over gloo" if host_transport

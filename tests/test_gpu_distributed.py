@@ -27,7 +27,7 @@ def test_bench_gpus_2_starts_its_own_ranks_over_the_host_transport():
     import json
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--points", "200000",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong", "--transport", "host", "--points", "200000",
            "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -42,6 +42,30 @@ def test_bench_gpus_2_starts_its_own_ranks_over_the_host_transport():
     assert d["rmse_end"] < d["rmse_start"]
 
 
+def test_bench_gpus_2_default_is_weak_scaling_of_the_headline_workload():
+    """`python bench.py --gpus 2` as the driver runs it (no workload flags besides a reduced point count for the one-GPU box): a
+    config-3-shaped shard per rank -- 100 cameras, 10 %, `--points` per rank --, `scaling: weak`, and `value` = the units both
+    ranks processed / time = 2 x the joint problem's iterations per second, so that the driver's own `value(N) / (N value(1))`
+    is an efficiency."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--points", "100000",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "it/s"
+    c = d["config"]
+    assert c["cameras"] == 100 and c["visibility"] == 0.1 and c["points_total"] == 200000 and c["points_rank0"] == 100000
+    assert "one shard per GPU" in c["workload"]  # (a reduced point count: "custom scene"; the driver's run says "BASELINE config 3 shard per GPU")
+    assert d["value"] == pytest.approx(2 * c["joint_it_per_s"]) and c["joint_it_per_s"] == pytest.approx(1e3 / d["ms_per_step"])
+    assert d["allreduce"]["ranks"] == 2 and d["allreduce"]["bytes_per_solve"] == 8 * (81 * 100 * 101 // 2 + 9 * 100)
+    assert d["rmse_end"] < d["rmse_start"]
+
+
 def test_bench_gpus_3_non_power_of_two_split_over_the_host_transport():
     """The launcher path beyond two ranks: `python bench.py --gpus 3 --transport host` on config-4-shaped shards (500 cameras, 5 %,
     D = 4493) -- a non-power-of-two split by `scene_shard`, three rank processes under torch.distributed.run sharing the one GPU,
@@ -52,7 +76,7 @@ def test_bench_gpus_3_non_power_of_two_split_over_the_host_transport():
     import json
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--transport", "host", "--points", "300000",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--strong", "--transport", "host", "--points", "300000",
            "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
