@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(128) void k_schur_reduce(int m, const int *__restri
 //   G_a = [R_a^T J_Xak^T J~_ak]_k   (3 x 9m),        A = blockdiag(2 H_k + c diag(2 H_k)) - 4 sum_a G_a^T G_a,
 //   H_k = sum_a J~_ak^T J~_ak,                        b_k = 2 sum_a J~_ak^T (J_Xak E_a^-1 dP_a - e_ak)
 // -- one symmetric rank-3N update of a 9m x 9m matrix: a GEMM, on the f64 matrix cores, over records streamed ONCE.
-// A workgroup takes DCH points at a time: their records and point rows go into LDS with contiguous 16-byte loads; a thread per
+// A workgroup takes a chunk of points (dense_ch: 4 or 8) at a time: their records and point rows go into LDS with contiguous 16-byte loads; a thread per
 // observation forms J_X R and the right-hand-side vector w; the rows of G are written to LDS once (each is read by up to T tile
 // pairs); wave w then owns the 16 x 16 tile pairs w, w + 4, ... of the upper triangle (four consecutive rows of G -- of whichever
 // points -- are one v_mfma_f64_16x16x4: no padding of K) and the per-camera tiles [J~ | w]^T [J~ | w] (two points per MFMA) of the
@@ -1287,7 +1287,13 @@ typedef double mvba_d4 __attribute__((ext_vector_type(4)));
 #ifndef MVBA_DENSE_KO
 #define MVBA_DENSE_KO 0  // (timing-only builds: bit 0 no main MFMAs, 1 no rows of G, 2 no per-observation phase, 3 no per-camera MFMAs)
 #endif
-constexpr int DCH = 8;             // points per chunk
+// Points per chunk (= producer waves) and workgroups per CU.  Up to 7 tiles (12 cameras) the kernel needs at most 126 registers: four
+// waves fit a SIMD, so TWO 8-wave workgroups of 4-point chunks (~53 KB of LDS each) share a CU and fill each other's barrier waits
+// (1.335 -> 1.260 ms at 1 M x 12, 1.48 -> 1.32 at 2 M x 6; three workgroups: worse again).  8 tiles take 154 registers -- three waves
+// per SIMD -- and stay with one 12-wave workgroup of 8-point chunks (two of the small ones cannot both be resident: 1.65 -> 1.82 ms
+// at 14 cameras); beyond that eight consumer + four producer waves.  (tools/dense_ch.sh, profiles/r05_dense_form.txt)
+constexpr int dense_ch(int T) { return T == 8 ? 8 : 4; }
+constexpr int dense_wgs(int T) { return T <= 7 ? 2 : 1; }
 constexpr int DENSE_MAX_TILES = 12;  // 9 m <= 192: m <= 21 cameras (78 tile pairs: 20 accumulators of 4 doubles per lane)
 __device__ __forceinline__ int dense_tile_elem(int row, int col) { return ((row >> 2) << 6) | ((row & 3) << 4) | col; }  // C/D layout: col = l & 15, row = (l >> 4) + 4 reg
 
@@ -1353,11 +1359,11 @@ __device__ long long g_dense_trace[1024 * 16 * 4];  // per workgroup and wave: r
 #define DT_BARRIER() __syncthreads()
 #endif
 template <int T, bool TABLE>  // TABLE: the records of a point through obs_of (missing observations), otherwise one contiguous range
-__global__ __launch_bounds__(64 * (dense_consumers(T) + (T <= 8 ? DCH : DCH / 2))) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
+__global__ __launch_bounds__(64 * (dense_consumers(T) + dense_ch(T))) void k_schur_dense(const double2 *__restrict__ rec, const double *__restrict__ PB, const int *__restrict__ obs_of,
                                                      long long N, int m, double cu, double *__restrict__ part) {
   constexpr int NC = dense_consumers(T);           // consumer waves (4 + 8 producers up to 8 tiles, 8 + 4 beyond)
   constexpr int P = T * (T + 1) / 2, NPW = (P + NC - 1) / NC, W = 16 * T, NCW = ((16 * T) / 9 + NC - 1) / NC;
-  constexpr int CH = T <= 8 ? DCH : DCH / 2;       // points per chunk = producer waves (the double-buffered rows must fit the LDS beside each other)
+  constexpr int CH = dense_ch(T);       // points per chunk = producer waves (the double-buffered rows must fit the LDS beside each other)
   constexpr int MMAX = (16 * T) / 9;               // cameras at most
   constexpr int NTHR = 64 * (NC + CH);
   extern __shared__ double2 dsm[];
@@ -4459,7 +4465,7 @@ int mvba_create(const mvba_problem *p, mvba_handle **out) {
     int n_cu_dense = 256;
     hipDeviceGetAttribute(&n_cu_dense, hipDeviceAttributeMultiprocessorCount, h->device);
     h->dense_tiles = T * (T + 1) / 2 + m;
-    h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + (T <= 8 ? DCH : DCH / 2) - 1) / (T <= 8 ? DCH : DCH / 2), n_cu_dense));  // one workgroup (eight waves, ~110 KB of LDS) per CU
+    h->dense_blocks = (int)std::max<long long>(1, std::min<long long>((N + dense_ch(T) - 1) / dense_ch(T), (long long)n_cu_dense * dense_wgs(T)));  // dense_wgs workgroups per CU (LDS and registers: see dense_ch)
     TRY(dmalloc(&h->d_dense_part, (size_t)h->dense_blocks * h->dense_tiles * 256));
     if (!dense_obs.empty()) {
       TRY(dmalloc(&h->d_dense_obs, dense_obs.size()));
@@ -4712,7 +4718,7 @@ int mvba_try_step(mvba_handle *h, double c, double *E_trial) {
   } else if (h->schur_mode == SCHUR_DENSE) {
     Timed t(h, MVBA_K_SCHUR);
     const int T = (9 * m + 15) / 16;
-    const int CH = T <= 8 ? DCH : DCH / 2;
+    const int CH = dense_ch(T);
     const size_t lds = sizeof(double) * ((size_t)2 * 3 * CH * 16 * T + (size_t)2 * CH * m * 32) + sizeof(double2) * CH * ((size_t)m * REC + 8) + sizeof(double) * (CH * (size_t)m + 2 * 3 * CH);
     auto launch = [&](auto kern) {
       if (!h->dense_attr_set) {  // (once per engine; the limit of the INSTANTIATION -- its largest camera count -- so that engines with other m share it)
