@@ -22,13 +22,14 @@ eng.reset_stats()
 eng.try_step(1e-4)
 ms = eng.stats()["schur"]["ms"]
 lib = _mvba.load_library()
-tr = np.zeros(256 * 16 * 4, dtype=np.int64)
+tr = np.zeros(1024 * 16 * 4, dtype=np.int64)
 assert lib.mvba_dense_trace_read(tr.ctypes.data_as(C.c_void_p), tr.size) == 0
-tr = tr.reshape(256, 16, 4)
+tr = tr.reshape(1024, 16, 4)
+tr = tr[tr[:, 0, 2] > 0]  # the workgroups of this launch (256 or 512)
 T = (9 * m + 15) // 16
-nc = 4 if T <= 8 else 8
-cons, prod = tr[:, :nc], tr[:, nc:12]
-print(f"{n} x {m} x {vis}: K3 {ms:.3f} ms; chunks per workgroup {int(cons[:, 0, 3].mean())}")
+nc, ch = (4 if T <= 8 else 8), (8 if T == 8 else 4)  # consumer / producer waves (dense_consumers, dense_ch in mvba.hip)
+cons, prod = tr[:, :nc], tr[:, nc:nc + ch]
+print(f"{n} x {m} x {vis}: K3 {ms:.3f} ms; {len(tr)} workgroups, chunks per workgroup {int(cons[:, 0, 3].mean())}")
 for name, r in (("consumers", cons), ("producers", prod)):
     tot = r[..., 2].astype(float)
     print(f"  {name}: total ticks median {np.median(tot):.0f}; work {100 * np.median(r[..., 0] / tot):.1f} %  barrier wait {100 * np.median(r[..., 1] / tot):.1f} % "
