@@ -207,6 +207,19 @@ def allreduce_model(n_cams, ranks=8):
             "note": "bandwidth terms only (no launch / latency terms: +10-30 us per collective); every rank then solves the reduced system redundantly"}
 
 
+def weak_scaling_model(n_cams, ms_per_solve):
+    """What the all-reduce model says the driver's N = 2, 4, 8 points of the weak series (`--gpus N`: a config-3-sized shard per GPU)
+    will be, from THIS run's ms per solve: per-solve time + one all-reduce of the packed reduced system (bandwidth over one ring
+    link + 30 us of launch / latency per collective) + the 16-byte cost gather (10 us).  A MODEL, labelled as such: no multi-GPU
+    node has run this bench yet."""
+    out = {"note": "model, not a measurement: ms_per_solve of this run + ring all-reduce over one xGMI link (153 GB/s) + 30 us + 10 us "
+                   "for the cost gather; efficiency = value(N) / (N value(1)) of the weak series"}
+    for n in (2, 4, 8):
+        ar = allreduce_model(n_cams, n)["ring_one_link_ms"] + 0.030 + 0.010
+        out[str(n)] = {"allreduce_ms": ar, "efficiency": ms_per_solve / (ms_per_solve + ar)}
+    return out
+
+
 def config4_shard_leg(device, steps=3):
     """BASELINE config 4's per-GPU shard (1.25 M points x 500 cameras x 5 % = 1/8 of the scene, no exchange) on the one GPU of an
     N = 1 run: the only hardware evidence for the multi-GPU configuration while no 8-GPU node runs the bench.  One warm-up LM
@@ -787,6 +800,7 @@ def main():
                            "bytes_per_solve": 8 * (81 * n_cams * (n_cams + 1) // 2 + 9 * n_cams), "ranks": world,
                            "transport": args.transport} if multi else None),
             "allreduce_model": allreduce_model(n_cams, max(world, 2)) if (multi or config4 or shard4) else None,
+            "weak_scaling_model": weak_scaling_model(n_cams, ms_solve) if (world == 1 and scaling == "weak" and not shard4) else None,
             "resid_jac_gobs_per_s": n_obs_total / (k1_ms * 1e-3) / 1e9,
             "inner_solves": n_solves,
             "ms_per_inner_solve": ms_solve,

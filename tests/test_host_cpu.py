@@ -181,6 +181,10 @@ def test_bench_round5_helpers_cores_allreduce_model_and_shard_roofline(monkeypat
     assert mdl["bytes_per_solve"] == 8 * (81 * 500 * 501 // 2 + 9 * 500) == 81_198_000
     assert mdl["ring_one_link_ms"] == pytest.approx(2 * 7 / 8 * 81_198_000 / 153e9 * 1e3)
     assert mdl["direct_all_links_ms"] == pytest.approx(2 * (81_198_000 / 8) / 153e9 * 1e3)
+    wk = bench.weak_scaling_model(100, 2.4)  # the weak series' N = 2, 4, 8 points as the all-reduce model prices them (3.28 MB per solve)
+    ar8 = 2 * 7 / 8 * 8 * (81 * 100 * 101 // 2 + 9 * 100) / 153e9 * 1e3 + 0.040
+    assert wk["8"]["allreduce_ms"] == pytest.approx(ar8) and wk["8"]["efficiency"] == pytest.approx(2.4 / (2.4 + ar8))
+    assert wk["2"]["efficiency"] > wk["4"]["efficiency"] > wk["8"]["efficiency"] > 0.95 and "model" in wk["note"]
     monkeypatch.setattr(bench, "pmc_traffic", lambda kernel, n_obs: (None, None))
     unit = bench.schur_roofline({"kernel": "pairs", "items": 421_000_000, "offdiag_items": 390_000_000, "units": 1_000_000, "slot_rows": 0},
                                 31_246_709, 13.7, 256)
